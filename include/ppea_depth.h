@@ -1,0 +1,142 @@
+/*
+ * ppea_depth.h -- C ABI of libppea_depth.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary of the PPEA-Depth training hot path.
+ * Every entry point replaces a stock ATen/cuDNN op sequence at the cited
+ * reference call site (paths relative to /root/reference/ppeadepth/).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers into contiguous row-major (NCHW) buffers
+ *     owned by the caller; kernels never allocate or free;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *     call only enqueues work on that stream and returns;
+ *   - the return value is a hipError_t (0 = hipSuccess); PPEA_ERR_UNSUPPORTED
+ *     (= -1) is returned for argument combinations the library does not serve;
+ *   - fp32 I/O entry points end in _f32, bf16 I/O (fp32 accumulate) in _bf16.
+ */
+#ifndef PPEA_DEPTH_H
+#define PPEA_DEPTH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPEA_ERR_UNSUPPORTED (-1)
+
+/* Library / build identification: returns the ABI version (bumped on any signature change). */
+int ppea_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * A1  Large-kernel depthwise convolution  (networks/replknet_adapter.py:151-168 get_conv2d,
+ *     :232-239 ReparamLargeKernelConv.forward).  stride 1, pad K/2, dilation 1, no bias.
+ *     x [N,C,H,W]; w_big [C,1,K,K]; w_small [C,1,KS,KS] or NULL (then y_small is ignored).
+ *     One launch produces both branches from one LDS-resident input tile.
+ *     K odd, 7 <= K <= 31; KS in {0 (absent), 3, 5}.
+ * ---------------------------------------------------------------------------------------- */
+int ppea_dwconv_lk_fwd_f32(const float* x, const float* w_big, const float* w_small,
+                           float* y_big, float* y_small,
+                           int N, int C, int H, int W, int K, int KS, void* stream);
+int ppea_dwconv_lk_fwd_bf16(const uint16_t* x, const float* w_big, const float* w_small,
+                            uint16_t* y_big, uint16_t* y_small,
+                            int N, int C, int H, int W, int K, int KS, void* stream);
+
+/* dgrad of the pair: dx = corr(dy_big, flip(w_big)) + corr(dy_small, flip(w_small)).
+ * dy_small / w_small may be NULL. */
+int ppea_dwconv_lk_bwd_data_f32(const float* dy_big, const float* dy_small,
+                                const float* w_big, const float* w_small, float* dx,
+                                int N, int C, int H, int W, int K, int KS, void* stream);
+int ppea_dwconv_lk_bwd_data_bf16(const uint16_t* dy_big, const uint16_t* dy_small,
+                                 const float* w_big, const float* w_small, uint16_t* dx,
+                                 int N, int C, int H, int W, int K, int KS, void* stream);
+
+/* wgrad (only needed with --fullft_reb, repdepth.py:47, and by the plug-in's weight.grad):
+ * dw[c,0,u,v] = sum_{n,i,j} dy[n,c,i,j] * x[n,c,i+u-K/2,j+v-K/2].  dw is overwritten. */
+int ppea_dwconv_lk_bwd_filter_f32(const float* x, const float* dy, float* dw,
+                                  int N, int C, int H, int W, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A18+A19  BackprojectDepth -> Project3D fused (layers.py:138-199; trainer.py:904-907).
+ *     depth [B,1,H,W]; inv_K [B,4,4] (only [:3,:3] read); P [B,3,4] = (K @ T)[:, :3, :];
+ *     grid [B,H,W,2] normalised to [-1,1] (x then y); eps added to z (1e-7).
+ *     bwd: d_depth [B,1,H,W] overwritten; dP [B,3,4] ACCUMULATED (caller zero-fills).
+ * ---------------------------------------------------------------------------------------- */
+int ppea_backproject_project_fwd_f32(const float* depth, const float* inv_K, const float* P,
+                                     float* grid, int B, int H, int W, float eps, void* stream);
+int ppea_backproject_project_bwd_f32(const float* depth, const float* inv_K, const float* P,
+                                     const float* d_grid, float* d_depth, float* dP,
+                                     int B, int H, int W, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A20  F.grid_sample(bilinear, align_corners=True)  (trainer.py:911-914 border;
+ *      replk_matching_adapter.py:299 zeros).  src [B,C,Hi,Wi]; grid [B,Ho,Wo,2];
+ *      out [B,C,Ho,Wo].  padding: 0 = zeros, 1 = border.
+ *      bwd_grid: gradient w.r.t. the grid only (the source is data).
+ * ---------------------------------------------------------------------------------------- */
+int ppea_grid_sample_fwd_f32(const float* src, const float* grid, float* out,
+                             int B, int C, int Hi, int Wi, int Ho, int Wo, int padding,
+                             void* stream);
+int ppea_grid_sample_bwd_grid_f32(const float* src, const float* grid, const float* d_out,
+                                  float* d_grid, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                                  int padding, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A21+A22  compute_reprojection_loss (trainer.py:995-1007; SSIM layers.py:226-257):
+ *      out[b,0,i,j] = alpha * mean_c SSIM(pred,target) + (1-alpha) * mean_c |target-pred|.
+ *      pred/target [B,C,H,W] (H,W >= 2); out has batch stride `out_bstride` elements so the
+ *      result can be written straight into one channel of a [B,2,H,W] buffer.
+ *      bwd: gradient w.r.t. pred (d_out has batch stride dout_bstride).
+ * ---------------------------------------------------------------------------------------- */
+int ppea_ssim_l1_fwd_f32(const float* pred, const float* target, float* out, long out_bstride,
+                         int B, int C, int H, int W, float alpha, void* stream);
+int ppea_ssim_l1_bwd_f32(const float* pred, const float* target, const float* d_out,
+                         long dout_bstride, float* d_pred, int B, int C, int H, int W,
+                         float alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A23  get_smooth_loss (layers.py:210-223).  disp [B,1,H,W], img [B,C,H,W].
+ *      sums[0] += sum |dx disp| e^{-mean_c|dx img|}, sums[1] += same for dy (ACCUMULATED;
+ *      caller zero-fills and divides by the element counts B*H*(W-1), B*(H-1)*W).
+ *      bwd: d_disp = gx * d(sum_x)/d(disp) + gy * d(sum_y)/d(disp) with scalar weights.
+ * ---------------------------------------------------------------------------------------- */
+int ppea_smooth_fwd_f32(const float* disp, const float* img, float* sums,
+                        int B, int C, int H, int W, void* stream);
+int ppea_smooth_bwd_f32(const float* disp, const float* img, float gx, float gy, float* d_disp,
+                        int B, int C, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A24/A25  per-pixel loss selection (trainer.py:1069-1114): min over the two source frames,
+ *      selec_reproj overwrite, identity min + tie-break noise, automask argmin.
+ *      reproj, identity [B,2,H,W]; warped_m1/p1 [B,3,H,W]; noise [B,1,H,W] (already * 1e-5) or
+ *      NULL.  Outputs: sel [B,1,H,W] selected reprojection loss; src_idx uint8 [B,1,H,W]
+ *      (0/1 = which of reproj's two channels feeds `sel`, 2 = forced zero);
+ *      frame_idx int64 [B,1,H,W] (argmin over the two frames, first minimum);
+ *      auto_idx int64 [B,1,H,W] (argmin over [sel, identity_min+noise], first minimum).
+ * ---------------------------------------------------------------------------------------- */
+int ppea_loss_select_f32(const float* reproj, const float* identity, const float* warped_m1,
+                         const float* warped_p1, const float* noise, float* sel,
+                         uint8_t* src_idx, int64_t* frame_idx, int64_t* auto_idx,
+                         int B, int C, int H, int W, int selec_reproj, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A9  match_features (replk_matching_adapter.py:261-340), one lookup frame per item.
+ *      cur, lookup [B,C,h,w]; P [B,3,4] = (K @ T)[:, :3, :] at the matching scale;
+ *      inv_K [B,4,4]; bins [D]; skip [B] int32 (non-zero = lookup pose was zeroed, item skipped
+ *      -> cost 0).  cost [B,D,h,w] = mean_c|warp(lookup) - cur| * edge_mask / (cnt + 1e-7).
+ * A10 cost_volume_reduce (:446-456, :372-387): missing -> per-pixel max; confidence mask;
+ *      argmin over bins after 0 -> 100 (int64, first minimum); lowest = 1/bins[argmin];
+ *      cost_out = filled cost * confidence.
+ * ---------------------------------------------------------------------------------------- */
+int ppea_cost_volume_fwd_f32(const float* cur, const float* lookup, const float* P,
+                             const float* inv_K, const float* bins, const int32_t* skip,
+                             float* cost, int B, int C, int h, int w, int D, float eps,
+                             void* stream);
+int ppea_cost_volume_reduce_f32(const float* cost, const float* bins, float* cost_out,
+                                float* confidence, int64_t* argmin, float* lowest,
+                                int B, int D, int h, int w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPEA_DEPTH_H */

@@ -1,0 +1,238 @@
+// Geometry of the photometric warp, gfx950:
+//   A18+A19  BackprojectDepth -> Project3D fused        (layers.py:138-199)
+//   A20      F.grid_sample bilinear, align_corners=True  (trainer.py:911-914, rkm.py:299)
+// All HBM-bound streaming kernels: one thread per output pixel, coalesced NCHW rows,
+// no intermediate [B,4,HW] point cloud (the reference writes ~5 MB/img for 1.5 MB
+// of algorithmic traffic; here depth is read once and the grid written once).
+#include "common.h"
+
+namespace {
+
+struct Cam {            // per-batch matrices broadcast through SGPRs
+    float ik[9];        // inv_K[:3,:3]
+    float p[12];        // P = (K @ T)[:3,:4]
+};
+
+__device__ __forceinline__ Cam load_cam(const float* __restrict__ inv_K, const float* __restrict__ P, int b) {
+    Cam c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c.ik[i * 3 + j] = inv_K[b * 16 + i * 4 + j];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) c.p[i] = P[b * 12 + i];
+    return c;
+}
+
+// ray = inv_K[:3,:3] @ (x, y, 1) with the reference's matmul association (k = 0,1,2).
+__device__ __forceinline__ void pixel_ray(const Cam& c, float x, float y, float (&r)[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r[i] = (c.ik[i * 3] * x + c.ik[i * 3 + 1] * y) + c.ik[i * 3 + 2];
+}
+
+__global__ __launch_bounds__(256) void backproject_project_fwd(const float* __restrict__ depth,
+                                                               const float* __restrict__ inv_K,
+                                                               const float* __restrict__ P,
+                                                               float* __restrict__ grid, int H, int W,
+                                                               float eps) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * W) return;
+    const Cam c = load_cam(inv_K, P, b);
+    const int py = i / W, px = i - py * W;
+    float r[3];
+    pixel_ray(c, (float)px, (float)py, r);
+    const float d = depth[(long)b * H * W + i];
+    const float X = d * r[0], Y = d * r[1], Z = d * r[2];
+    float cam[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        cam[k] = ((c.p[k * 4] * X + c.p[k * 4 + 1] * Y) + c.p[k * 4 + 2] * Z) + c.p[k * 4 + 3];
+    const float iz = cam[2] + eps;
+    float u = cam[0] / iz, v = cam[1] / iz;
+    u = u / (float)(W - 1);
+    v = v / (float)(H - 1);
+    float2 o;
+    o.x = (u - 0.5f) * 2.f;
+    o.y = (v - 0.5f) * 2.f;
+    reinterpret_cast<float2*>(grid)[(long)b * H * W + i] = o;
+}
+
+// d_depth (per pixel) and dP (12 sums per batch item: wave shuffle reduce -> LDS -> one atomic
+// per block and entry).
+__global__ __launch_bounds__(256) void backproject_project_bwd(const float* __restrict__ depth,
+                                                               const float* __restrict__ inv_K,
+                                                               const float* __restrict__ P,
+                                                               const float* __restrict__ d_grid,
+                                                               float* __restrict__ d_depth,
+                                                               float* __restrict__ dP, int H, int W,
+                                                               float eps) {
+    __shared__ float red[4][12];
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const Cam c = load_cam(inv_K, P, b);
+    float g[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) g[k] = 0.f;
+    if (i < H * W) {
+        const int py = i / W, px = i - py * W;
+        float r[3];
+        pixel_ray(c, (float)px, (float)py, r);
+        const float d = depth[(long)b * H * W + i];
+        const float Xh[4] = {d * r[0], d * r[1], d * r[2], 1.f};
+        float cam[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            cam[k] = ((c.p[k * 4] * Xh[0] + c.p[k * 4 + 1] * Xh[1]) + c.p[k * 4 + 2] * Xh[2]) + c.p[k * 4 + 3];
+        const float iz = 1.f / (cam[2] + eps);
+        const float u = cam[0] * iz, v = cam[1] * iz;
+        const float2 dg = reinterpret_cast<const float2*>(d_grid)[(long)b * H * W + i];
+        const float du = dg.x * 2.f / (float)(W - 1), dv = dg.y * 2.f / (float)(H - 1);
+        const float dc[3] = {du * iz, dv * iz, -(du * u + dv * v) * iz};
+        float dX[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dX[j] = c.p[j] * dc[0] + c.p[4 + j] * dc[1] + c.p[8 + j] * dc[2];
+        d_depth[(long)b * H * W + i] = dX[0] * r[0] + dX[1] * r[1] + dX[2] * r[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[k * 4 + j] = dc[k] * Xh[j];
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const float s = wave_sum(g[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        atomicAdd(dP + b * 12 + threadIdx.x, s);
+    }
+}
+
+// ---- grid_sample -----------------------------------------------------------------------
+struct Tap {
+    int x0, y0;
+    float tx, ty;       // fractional parts
+    float mx, my;       // d(ix)/d(grid.x), d(iy)/d(grid.y) incl. the border clip gate
+};
+
+__device__ __forceinline__ Tap make_tap(float gx, float gy, int Wi, int Hi, bool border) {
+    // align_corners=True un-normalisation: ix = (x + 1) / 2 * (W - 1)
+    float ix = ((gx + 1.f) / 2.f) * (float)(Wi - 1);
+    float iy = ((gy + 1.f) / 2.f) * (float)(Hi - 1);
+    Tap t;
+    t.mx = (float)(Wi - 1) / 2.f;
+    t.my = (float)(Hi - 1) / 2.f;
+    if (border) {       // clip_coordinates_set_grad: zero gradient at and beyond the rim
+        if (!(ix > 0.f)) { ix = 0.f; t.mx = 0.f; } else if (ix >= (float)(Wi - 1)) { ix = (float)(Wi - 1); t.mx = 0.f; }
+        if (!(iy > 0.f)) { iy = 0.f; t.my = 0.f; } else if (iy >= (float)(Hi - 1)) { iy = (float)(Hi - 1); t.my = 0.f; }
+    }
+    const float fx = floorf(ix), fy = floorf(iy);
+    t.tx = ix - fx;
+    t.ty = iy - fy;
+    // far-out-of-range coordinates (zeros mode): keep the int conversion defined; all four
+    // corners are then outside the image and contribute 0.
+    t.x0 = (int)fminf(fmaxf(fx, -4.f), (float)Wi + 4.f);
+    t.y0 = (int)fminf(fmaxf(fy, -4.f), (float)Hi + 4.f);
+    return t;
+}
+
+__device__ __forceinline__ float fetch(const float* __restrict__ plane, int x, int y, int Wi, int Hi) {
+    return (x >= 0 && x < Wi && y >= 0 && y < Hi) ? plane[(long)y * Wi + x] : 0.f;
+}
+
+template <int CMAX>
+__global__ __launch_bounds__(256) void grid_sample_fwd(const float* __restrict__ src,
+                                                       const float* __restrict__ grid,
+                                                       float* __restrict__ out, int C, int Hi, int Wi,
+                                                       int Ho, int Wo, int border) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Ho * Wo) return;
+    const float2 g = reinterpret_cast<const float2*>(grid)[(long)b * Ho * Wo + i];
+    const Tap t = make_tap(g.x, g.y, Wi, Hi, border != 0);
+    // weights exactly as ATen: nw = (x1 - ix)(y1 - iy) etc.
+    const float wx1 = t.tx, wx0 = 1.f - t.tx, wy1 = t.ty, wy0 = 1.f - t.ty;
+    for (int c = 0; c < C; ++c) {
+        const float* plane = src + ((long)b * C + c) * Hi * Wi;
+        const float v00 = fetch(plane, t.x0, t.y0, Wi, Hi), v01 = fetch(plane, t.x0 + 1, t.y0, Wi, Hi);
+        const float v10 = fetch(plane, t.x0, t.y0 + 1, Wi, Hi), v11 = fetch(plane, t.x0 + 1, t.y0 + 1, Wi, Hi);
+        out[((long)b * C + c) * Ho * Wo + i] = ((v00 * (wx0 * wy0) + v01 * (wx1 * wy0)) + v10 * (wx0 * wy1)) + v11 * (wx1 * wy1);
+    }
+}
+
+__global__ __launch_bounds__(256) void grid_sample_bwd_grid(const float* __restrict__ src,
+                                                            const float* __restrict__ grid,
+                                                            const float* __restrict__ d_out,
+                                                            float* __restrict__ d_grid, int C, int Hi,
+                                                            int Wi, int Ho, int Wo, int border) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Ho * Wo) return;
+    const float2 g = reinterpret_cast<const float2*>(grid)[(long)b * Ho * Wo + i];
+    const Tap t = make_tap(g.x, g.y, Wi, Hi, border != 0);
+    float gx = 0.f, gy = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float* plane = src + ((long)b * C + c) * Hi * Wi;
+        const float v00 = fetch(plane, t.x0, t.y0, Wi, Hi), v01 = fetch(plane, t.x0 + 1, t.y0, Wi, Hi);
+        const float v10 = fetch(plane, t.x0, t.y0 + 1, Wi, Hi), v11 = fetch(plane, t.x0 + 1, t.y0 + 1, Wi, Hi);
+        const float go = d_out[((long)b * C + c) * Ho * Wo + i];
+        gx += go * ((v01 - v00) * (1.f - t.ty) + (v11 - v10) * t.ty);
+        gy += go * ((v10 - v00) * (1.f - t.tx) + (v11 - v01) * t.tx);
+    }
+    float2 o;
+    o.x = gx * t.mx;
+    o.y = gy * t.my;
+    reinterpret_cast<float2*>(d_grid)[(long)b * Ho * Wo + i] = o;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ppea_backproject_project_fwd_f32(const float* depth, const float* inv_K, const float* P, float* grid,
+                                     int B, int H, int W, float eps, void* stream) {
+    if (B < 0 || H < 2 || W < 2) return PPEA_ERR_UNSUPPORTED;
+    if (B == 0) return 0;
+    dim3 g((H * W + 255) / 256, B);
+    hipLaunchKernelGGL(backproject_project_fwd, g, dim3(256), 0, (hipStream_t)stream, depth, inv_K, P, grid,
+                       H, W, eps);
+    return launch_status();
+}
+
+int ppea_backproject_project_bwd_f32(const float* depth, const float* inv_K, const float* P,
+                                     const float* d_grid, float* d_depth, float* dP, int B, int H, int W,
+                                     float eps, void* stream) {
+    if (B < 0 || H < 2 || W < 2) return PPEA_ERR_UNSUPPORTED;
+    if (B == 0) return 0;
+    dim3 g((H * W + 255) / 256, B);
+    hipLaunchKernelGGL(backproject_project_bwd, g, dim3(256), 0, (hipStream_t)stream, depth, inv_K, P,
+                       d_grid, d_depth, dP, H, W, eps);
+    return launch_status();
+}
+
+int ppea_grid_sample_fwd_f32(const float* src, const float* grid, float* out, int B, int C, int Hi, int Wi,
+                             int Ho, int Wo, int padding, void* stream) {
+    if (B < 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || (padding != 0 && padding != 1))
+        return PPEA_ERR_UNSUPPORTED;
+    if (B == 0) return 0;
+    dim3 g((Ho * Wo + 255) / 256, B);
+    hipLaunchKernelGGL(grid_sample_fwd<0>, g, dim3(256), 0, (hipStream_t)stream, src, grid, out, C, Hi, Wi,
+                       Ho, Wo, padding);
+    return launch_status();
+}
+
+int ppea_grid_sample_bwd_grid_f32(const float* src, const float* grid, const float* d_out, float* d_grid,
+                                  int B, int C, int Hi, int Wi, int Ho, int Wo, int padding, void* stream) {
+    if (B < 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || (padding != 0 && padding != 1))
+        return PPEA_ERR_UNSUPPORTED;
+    if (B == 0) return 0;
+    dim3 g((Ho * Wo + 255) / 256, B);
+    hipLaunchKernelGGL(grid_sample_bwd_grid, g, dim3(256), 0, (hipStream_t)stream, src, grid, d_out, d_grid,
+                       C, Hi, Wi, Ho, Wo, padding);
+    return launch_status();
+}
+
+}  // extern "C"

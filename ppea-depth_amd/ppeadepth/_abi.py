@@ -1,0 +1,91 @@
+"""ctypes binding of libppea_depth.so (C ABI: include/ppea_depth.h).
+
+This is the only place the product talks to native code.  There is NO fallback:
+if the shared library is missing or an entry point is absent, importing this module
+raises, and every op refuses tensors that are not resident on a HIP device.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libppea_depth.so")
+
+ABI_VERSION = 1
+
+_vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+
+# name -> argtypes (restype is always int = hipError_t); mirrors include/ppea_depth.h
+SIGNATURES = {
+    "ppea_abi_version": [],
+    "ppea_dwconv_lk_fwd_f32": [_vp] * 5 + [_i] * 6 + [_vp],
+    "ppea_dwconv_lk_fwd_bf16": [_vp] * 5 + [_i] * 6 + [_vp],
+    "ppea_dwconv_lk_bwd_data_f32": [_vp] * 5 + [_i] * 6 + [_vp],
+    "ppea_dwconv_lk_bwd_data_bf16": [_vp] * 5 + [_i] * 6 + [_vp],
+    "ppea_dwconv_lk_bwd_filter_f32": [_vp] * 3 + [_i] * 5 + [_vp],
+    "ppea_backproject_project_fwd_f32": [_vp] * 4 + [_i] * 3 + [_f, _vp],
+    "ppea_backproject_project_bwd_f32": [_vp] * 6 + [_i] * 3 + [_f, _vp],
+    "ppea_grid_sample_fwd_f32": [_vp] * 3 + [_i] * 7 + [_vp],
+    "ppea_grid_sample_bwd_grid_f32": [_vp] * 4 + [_i] * 7 + [_vp],
+    "ppea_ssim_l1_fwd_f32": [_vp, _vp, _vp, _l] + [_i] * 4 + [_f, _vp],
+    "ppea_ssim_l1_bwd_f32": [_vp, _vp, _vp, _l, _vp] + [_i] * 4 + [_f, _vp],
+    "ppea_smooth_num_partials": [],
+    "ppea_smooth_fwd_f32": [_vp] * 3 + [_i] * 4 + [_vp],
+    "ppea_smooth_bwd_f32": [_vp, _vp, _f, _f, _vp] + [_i] * 4 + [_vp],
+    "ppea_loss_select_f32": [_vp] * 9 + [_i] * 5 + [_vp],
+    "ppea_cost_volume_fwd_f32": [_vp] * 7 + [_i] * 5 + [_f, _vp],
+    "ppea_cost_volume_reduce_f32": [_vp] * 6 + [_i] * 4 + [_vp],
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C ppea-depth_amd/csrc). "
+            "There is no CPU / PyTorch fallback for the PPEA-Depth hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    got = lib.ppea_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libppea_depth.so ABI {got} != expected {ABI_VERSION}: rebuild")
+    return lib
+
+
+lib = _load()
+
+
+class PpeaKernelError(RuntimeError):
+    pass
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PpeaKernelError("PPEA-Depth HIP kernels need tensors on a HIP device "
+                              "(no CPU fallback); got a CPU tensor")
+    if not t.is_contiguous():
+        raise PpeaKernelError("non-contiguous tensor passed to a HIP kernel")
+    if dtype is not None and t.dtype != dtype:
+        raise PpeaKernelError(f"expected {dtype}, got {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def check(err, name):
+    if err != 0:
+        what = "unsupported argument combination" if err == -1 else f"hipError_t {err}"
+        raise PpeaKernelError(f"{name} failed: {what}")
+
+
+def call(name, *args):
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,278 @@
+"""Autograd operators over the C ABI (include/ppea_depth.h).  Host glue only: every
+forward/backward below is one (or two) kernel launches on the current HIP stream.
+
+Reference call sites are cited per op (paths relative to /root/reference/ppeadepth/).
+"""
+import torch
+
+from . import _abi
+from ._abi import call, ptr, stream_ptr
+
+_F32 = torch.float32
+_BF16 = torch.bfloat16
+
+
+def _suffix(t):
+    if t.dtype == _F32:
+        return "f32"
+    if t.dtype == _BF16:
+        return "bf16"
+    raise _abi.PpeaKernelError(f"unsupported dtype {t.dtype}")
+
+
+# ---------------------------------------------------------------------------------------------
+# A1  large-kernel depthwise conv (+ fused 5x5 branch)   networks/replknet_adapter.py:151-168, 232-239
+# ---------------------------------------------------------------------------------------------
+class _DwConvLK(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_big, w_small):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        K = w_big.shape[-1]
+        KS = 0 if w_small is None else w_small.shape[-1]
+        wb = w_big.detach().to(_F32).contiguous()
+        ws = None if w_small is None else w_small.detach().to(_F32).contiguous()
+        y_big = torch.empty_like(x)
+        y_small = torch.empty_like(x) if KS else None
+        call(f"ppea_dwconv_lk_fwd_{_suffix(x)}", ptr(x), ptr(wb, _F32), ptr(ws), ptr(y_big), ptr(y_small),
+             N, C, H, W, K, KS, stream_ptr())
+        ctx.save_for_backward(x, wb, ws)
+        ctx.has_small = KS > 0
+        ctx.w_dtypes = (w_big.dtype, None if w_small is None else w_small.dtype)
+        if KS:
+            return y_big, y_small
+        return y_big, None
+
+    @staticmethod
+    def backward(ctx, dy_big, dy_small):
+        x, wb, ws = ctx.saved_tensors
+        N, C, H, W = x.shape
+        K = wb.shape[-1]
+        KS = ws.shape[-1] if ctx.has_small else 0
+        dx = dwb = dws = None
+        if dy_big is None:
+            dy_big = torch.zeros_like(x)
+        dy_big = dy_big.contiguous().to(x.dtype)
+        if ctx.has_small:
+            dy_small = (torch.zeros_like(x) if dy_small is None else dy_small.contiguous().to(x.dtype))
+        else:
+            dy_small = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call(f"ppea_dwconv_lk_bwd_data_{_suffix(x)}", ptr(dy_big), ptr(dy_small), ptr(wb), ptr(ws),
+                 ptr(dx), N, C, H, W, K, KS, stream_ptr())
+        if ctx.needs_input_grad[1]:
+            dwb = torch.empty_like(wb)
+            call("ppea_dwconv_lk_bwd_filter_f32", ptr(x.float().contiguous()), ptr(dy_big.float().contiguous()),
+                 ptr(dwb), N, C, H, W, K, stream_ptr())
+            dwb = dwb.to(ctx.w_dtypes[0])
+        if ctx.has_small and ctx.needs_input_grad[2]:
+            dws = torch.empty_like(ws)
+            call("ppea_dwconv_lk_bwd_filter_f32", ptr(x.float().contiguous()),
+                 ptr(dy_small.float().contiguous()), ptr(dws), N, C, H, W, KS, stream_ptr())
+            dws = dws.to(ctx.w_dtypes[1])
+        return dx, dwb, dws
+
+
+def dwconv_lk(x, w_big, w_small=None):
+    """(DW_k(x), DW_ks(x)) with stride 1 / pad k//2 / no bias; second is None without w_small."""
+    return _DwConvLK.apply(x, w_big, w_small)
+
+
+# ---------------------------------------------------------------------------------------------
+# A18+A19  BackprojectDepth -> Project3D                         layers.py:138-199
+# ---------------------------------------------------------------------------------------------
+class _BackprojectProject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, inv_K, P, eps):
+        depth = depth.contiguous().float()
+        inv_K = inv_K.contiguous().float()
+        P = P.contiguous().float()
+        B, _, H, W = depth.shape
+        grid = torch.empty(B, H, W, 2, device=depth.device, dtype=_F32)
+        call("ppea_backproject_project_fwd_f32", ptr(depth), ptr(inv_K), ptr(P), ptr(grid), B, H, W,
+             float(eps), stream_ptr())
+        ctx.save_for_backward(depth, inv_K, P)
+        ctx.eps = float(eps)
+        return grid
+
+    @staticmethod
+    def backward(ctx, d_grid):
+        depth, inv_K, P = ctx.saved_tensors
+        B, _, H, W = depth.shape
+        d_depth = torch.empty_like(depth)
+        dP = torch.zeros_like(P)
+        call("ppea_backproject_project_bwd_f32", ptr(depth), ptr(inv_K), ptr(P),
+             ptr(d_grid.contiguous().float()), ptr(d_depth), ptr(dP), B, H, W, ctx.eps, stream_ptr())
+        return d_depth, None, dP, None
+
+
+def backproject_project(depth, inv_K, K, T, eps=1e-7):
+    """depth [B,1,H,W] -> sampling grid [B,H,W,2];  P = (K @ T)[:, :3] keeps the pose gradient."""
+    P = torch.matmul(K, T)[:, :3, :]
+    return _BackprojectProject.apply(depth, inv_K, P, eps)
+
+
+# ---------------------------------------------------------------------------------------------
+# A20  grid_sample (bilinear, align_corners=True)            trainer.py:911-914, rkm.py:299
+# ---------------------------------------------------------------------------------------------
+class _GridSample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, grid, padding):
+        src = src.contiguous().float()
+        grid = grid.contiguous().float()
+        B, C, Hi, Wi = src.shape
+        _, Ho, Wo, _ = grid.shape
+        out = torch.empty(B, C, Ho, Wo, device=src.device, dtype=_F32)
+        call("ppea_grid_sample_fwd_f32", ptr(src), ptr(grid), ptr(out), B, C, Hi, Wi, Ho, Wo, padding,
+             stream_ptr())
+        ctx.save_for_backward(src, grid)
+        ctx.padding = padding
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        src, grid = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise _abi.PpeaKernelError("grid_sample: gradient w.r.t. the source image is not part of the "
+                                       "hot path (sources are input frames)")
+        B, C, Hi, Wi = src.shape
+        _, Ho, Wo, _ = grid.shape
+        d_grid = torch.empty_like(grid)
+        call("ppea_grid_sample_bwd_grid_f32", ptr(src), ptr(grid), ptr(d_out.contiguous().float()),
+             ptr(d_grid), B, C, Hi, Wi, Ho, Wo, ctx.padding, stream_ptr())
+        return None, d_grid, None
+
+
+def grid_sample(src, grid, padding_mode="border"):
+    return _GridSample.apply(src, grid, {"zeros": 0, "border": 1}[padding_mode])
+
+
+# ---------------------------------------------------------------------------------------------
+# A21+A22  reprojection loss                             trainer.py:995-1007, layers.py:226-257
+# ---------------------------------------------------------------------------------------------
+class _SsimL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, alpha):
+        pred = pred.contiguous().float()
+        target = target.contiguous().float()
+        B, C, H, W = pred.shape
+        out = torch.empty(B, 1, H, W, device=pred.device, dtype=_F32)
+        call("ppea_ssim_l1_fwd_f32", ptr(pred), ptr(target), ptr(out), H * W, B, C, H, W, float(alpha),
+             stream_ptr())
+        ctx.save_for_backward(pred, target)
+        ctx.alpha = float(alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        pred, target = ctx.saved_tensors
+        B, C, H, W = pred.shape
+        d_pred = torch.empty_like(pred)
+        call("ppea_ssim_l1_bwd_f32", ptr(pred), ptr(target), ptr(d_out.contiguous().float()), H * W,
+             ptr(d_pred), B, C, H, W, ctx.alpha, stream_ptr())
+        return d_pred, None, None
+
+
+def ssim_l1(pred, target, alpha=0.85):
+    """alpha * mean_C SSIM(pred, target) + (1-alpha) * mean_C |target - pred| -> [B,1,H,W].
+    Differentiable w.r.t. pred only (target is an input frame)."""
+    return _SsimL1.apply(pred, target, alpha)
+
+
+# ---------------------------------------------------------------------------------------------
+# A23  edge-aware smoothness                                         layers.py:210-223
+# ---------------------------------------------------------------------------------------------
+class _SmoothLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, img):
+        disp = disp.contiguous().float()
+        img = img.contiguous().float()
+        B, C, H, W = img.shape
+        nb = _abi.lib.ppea_smooth_num_partials()
+        partials = torch.empty(nb, 2, device=disp.device, dtype=_F32)
+        call("ppea_smooth_fwd_f32", ptr(disp), ptr(img), ptr(partials), B, C, H, W, stream_ptr())
+        s = partials.sum(0)
+        ctx.save_for_backward(disp, img)
+        ctx.nx = float(B * H * (W - 1))
+        ctx.ny = float(B * (H - 1) * W)
+        return s[0] / ctx.nx + s[1] / ctx.ny
+
+    @staticmethod
+    def backward(ctx, g):
+        disp, img = ctx.saved_tensors
+        B, C, H, W = img.shape
+        d_disp = torch.empty_like(disp)
+        call("ppea_smooth_bwd_f32", ptr(disp), ptr(img), 1.0 / ctx.nx, 1.0 / ctx.ny, ptr(d_disp), B, C, H, W,
+             stream_ptr())
+        return d_disp * g, None      # upstream scalar stays on the device (no host sync)
+
+
+def smooth_loss(disp, img):
+    return _SmoothLoss.apply(disp, img)
+
+
+# ---------------------------------------------------------------------------------------------
+# A24/A25  per-pixel selection                                     trainer.py:1069-1091
+# ---------------------------------------------------------------------------------------------
+class _LossSelect(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, reproj, identity, warped_m1, warped_p1, noise, selec):
+        reproj = reproj.contiguous().float()
+        B, _, H, W = reproj.shape
+        C = warped_m1.shape[1]
+        dev = reproj.device
+        sel = torch.empty(B, 1, H, W, device=dev, dtype=_F32)
+        src = torch.empty(B, 1, H, W, device=dev, dtype=torch.uint8)
+        fidx = torch.empty(B, 1, H, W, device=dev, dtype=torch.int64)
+        aidx = torch.empty(B, 1, H, W, device=dev, dtype=torch.int64)
+        call("ppea_loss_select_f32", ptr(reproj), ptr(identity.contiguous().float()),
+             ptr(warped_m1.contiguous().float()), ptr(warped_p1.contiguous().float()),
+             ptr(None if noise is None else noise.contiguous().float()), ptr(sel), ptr(src), ptr(fidx),
+             ptr(aidx), B, C, H, W, int(bool(selec)), stream_ptr())
+        ctx.save_for_backward(src)
+        ctx.mark_non_differentiable(src, fidx, aidx)
+        return sel, src, fidx, aidx
+
+    @staticmethod
+    def backward(ctx, d_sel, _a, _b, _c):
+        (src,) = ctx.saved_tensors
+        d = torch.cat([d_sel * (src == 0), d_sel * (src == 1)], 1)
+        return d, None, None, None, None, None
+
+
+def loss_select(reproj, identity, warped_m1, warped_p1, noise, selec_reproj=True):
+    """-> (selected reprojection loss [B,1,H,W], source idx u8, frame argmin i64, automask argmin i64)."""
+    return _LossSelect.apply(reproj, identity, warped_m1, warped_p1, noise, selec_reproj)
+
+
+# ---------------------------------------------------------------------------------------------
+# A9/A10  cost volume (runs under no_grad in the reference, rkm.py:427)
+# ---------------------------------------------------------------------------------------------
+@torch.no_grad()
+def cost_volume(cur, lookup, poses, K, inv_K, bins, eps=1e-7):
+    """cur, lookup [B,C,h,w]; poses [B,4,4] (zeroed pose = skipped item); -> raw cost [B,D,h,w]."""
+    cur = cur.contiguous().float()
+    lookup = lookup.contiguous().float()
+    B, C, h, w = cur.shape
+    D = bins.shape[0]
+    P = torch.matmul(K, poses)[:, :3, :].contiguous().float()
+    skip = (poses.reshape(B, -1).sum(1) == 0).to(torch.int32)
+    cost = torch.empty(B, D, h, w, device=cur.device, dtype=_F32)
+    call("ppea_cost_volume_fwd_f32", ptr(cur), ptr(lookup), ptr(P), ptr(inv_K.contiguous().float()),
+         ptr(bins.contiguous().float()), ptr(skip), ptr(cost), B, C, h, w, D, float(eps), stream_ptr())
+    return cost
+
+
+@torch.no_grad()
+def cost_volume_reduce(cost, bins):
+    """-> (masked cost [B,D,h,w], confidence [B,h,w], argmin int64 [B,h,w], lowest-cost 1/depth [B,h,w])."""
+    B, D, h, w = cost.shape
+    dev = cost.device
+    out = torch.empty_like(cost)
+    conf = torch.empty(B, h, w, device=dev, dtype=_F32)
+    idx = torch.empty(B, h, w, device=dev, dtype=torch.int64)
+    low = torch.empty(B, h, w, device=dev, dtype=_F32)
+    call("ppea_cost_volume_reduce_f32", ptr(cost.contiguous()), ptr(bins.contiguous().float()), ptr(out),
+         ptr(conf), ptr(idx), ptr(low), B, D, h, w, stream_ptr())
+    return out, conf, idx, low
