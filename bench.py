@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training img/s at 640x192, RepLKNet-31B Stage-1 (BASELINE.json config 2/3).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One rank per GPU (RCCL).  A "step" = Trainer.process_batch (teacher + multi-frame forward, both
+photometric losses) + backward + gradient all-reduce + Adam step on a synthetic batch of 12 frame
+triplets per GPU already resident in HBM.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      31x31 depthwise-conv kernel (the kernel north_star names): algorithmic bytes per
+                launch / average launch duration measured with HIP events inside the timed steps.
+  cpu_baseline  the CPU oracle (oracle/ref_model.py, a restatement pinned to the reference's golden
+                vectors) timed on this host for one B=2 step (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ppea-depth_amd"))
+sys.path.insert(0, ROOT)
+
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TF = 157.3        # fp32 vector peak
+
+
+def cpu_baseline(seconds_budget=40.0):
+    """The oracle's full training step on the host CPU: B=2, 192x640, fp32 (config 1)."""
+    import types
+    from oracle import model_spec, ref_model, synth
+    B, H, W = 2, 192, 640
+    opt = types.SimpleNamespace(rep_size="b", g_blk=1.0, g_ffn=1.0, use_checkpoint=False, height=H, width=W,
+                                batch_size=B, num_depth_bins=96, min_depth=0.1, max_depth=100.0,
+                                disparity_smoothness=1e-3)
+    sd = {k: synth.synth_tensor(k, torch.empty(shape, dtype=dt))
+          for k, (shape, dt) in model_spec.state_spec("b").items()}
+    sd = ref_model.leaf_state_dict(sd, opt)
+    tr = ref_model.RefTrainer(ref_model.RefRepDepth(sd, opt), opt)
+    inputs = synth.make_inputs(B, H, W)
+    cores = torch.get_num_threads()
+    times = []
+    t_all = time.time()
+    for it in range(3):
+        for v in sd.values():
+            v.grad = None
+        random.seed(it)
+        t0 = time.time()
+        _, losses = tr.process_batch(dict(inputs))
+        losses["loss"].backward()
+        times.append(time.time() - t0)
+        if time.time() - t_all > seconds_budget:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": round(B / best, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} x (process_batch + backward), B=2, 192x640, RepLKNet-31B fp32, "
+                      f"torch-CPU oracle, best of the non-first iterations ({best:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=12, help="per-GPU batch (reference --batch_size)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--rep_size", default="b", choices=["b", "l"])
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    args = ap.parse_args()
+
+    from ppeadepth import dist as pdist
+    from ppeadepth import networks, options, ops, rng
+    from ppeadepth.trainer import Trainer
+    from oracle import synth
+
+    rank, local_rank, world = pdist.init_distributed()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    H, W, B = 192, 640, args.batch
+    opt = options.default_options(height=H, width=W, batch_size=B, rep_size=args.rep_size)
+    torch.manual_seed(0)
+    model = networks.RepDepth(opt)
+    synth.fill_state_dict(model)                 # deterministic random-init weights (no checkpoints offline)
+    model.to(device).train()
+    pdist.broadcast_module(model)
+    amp = torch.bfloat16 if args.dtype == "bf16" else None
+    trainer = Trainer(opt, model, device, amp_dtype=amp)
+    engine = pdist.TrainEngine(trainer)
+    rng.set_mode("device")
+    inputs = {k: v.to(device) for k, v in synth.make_inputs(B, H, W, seed=1234 + rank, smooth=True).items()}
+    random.seed(1000 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        engine.step(dict(inputs))
+    barrier()
+    ops.PROFILE_DWCONV = []                       # (K, start_event, end_event) per k=31 launch
+    t0 = time.time()
+    for _ in range(args.steps):
+        _, losses = engine.step(dict(inputs))
+    barrier()
+    dt = time.time() - t0
+    events, ops.PROFILE_DWCONV = ops.PROFILE_DWCONV, None
+    loss_val = float(losses["loss"])
+
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+
+    if rank == 0:
+        # ---- roofline of the 31x31 depthwise conv (fwd launches with the fused 5x5 branch) ------
+        es = 2 if args.dtype == "bf16" else 4
+        C0 = 128 if args.rep_size == "b" else 192
+        fwd = [s.elapsed_time(e) * 1e-3 for (kind, s, e) in events if kind == "fwd31"]
+        bwd = [s.elapsed_time(e) * 1e-3 for (kind, s, e) in events if kind == "bwd31"]
+        roof = None
+        if fwd:
+            t_k = sum(fwd) / len(fwd)
+            plane = B * C0 * 48 * 160
+            bytes_alg = plane * es * 3 + C0 * (961 + 25) * 4            # x in, y_big + y_small out, weights
+            flops = 2.0 * plane * (961 + 25)
+            roof = {"kernel": "dwconv_lk_kernel<k=31,+5x5 fused> fwd", "bound": "hbm",
+                    "achieved": round(bytes_alg / t_k / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(bytes_alg / t_k / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_us": round(t_k * 1e6, 1), "launches_timed": len(fwd),
+                    "algorithmic_bytes_per_launch": bytes_alg,
+                    "binding_roof": "fp32 vector FMA (AI ~ %d F/B)" % round(flops / bytes_alg),
+                    "valu_tflops": round(flops / t_k / 1e12, 1),
+                    "valu_frac": round(flops / t_k / 1e12 / VALU_PEAK_TF, 3),
+                    "dgrad_avg_launch_us": round(sum(bwd) / len(bwd) * 1e6, 1) if bwd else None}
+        line = {
+            "metric": "training img/s at 640x192 RepLKNet-31B" if args.rep_size == "b" else
+                      "training img/s at 640x192 RepLKNet-31L",
+            "value": round(world * B * args.steps / dt, 3), "unit": "img/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic (smoothed uniform frames, KITTI intrinsics; random-init weights)",
+            "config": {"workload": f"RepLKNet-31{args.rep_size.upper()} Stage-1 640x192, {B} frame triplets/GPU, "
+                                   "process_batch + backward + grad all-reduce + Adam",
+                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
+                       "use_checkpoint": "BN-stat replay, no recompute (288 GB HBM)"},
+            "final_loss": round(loss_val, 5),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline()
+            except Exception as ex:          # the baseline must never take the bench line down
+                line["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

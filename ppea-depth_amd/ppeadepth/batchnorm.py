@@ -1,0 +1,147 @@
+"""Training-mode batch normalisation for the RepLKNet encoders.
+
+Reference semantics (networks/replknet_adapter.py:170-180): every BN of both encoders is an
+`nn.SyncBatchNorm` (the global `use_sync_bn` flag is set by the matching encoder and never
+reset) -- batch statistics over the GLOBAL batch (all ranks), running stats updated with
+momentum 0.1 and the unbiased variance.  `state_dict` keys are those of nn.BatchNorm2d.
+
+MI355X design notes
+  * one rank: `torch.native_batch_norm` (a single fused kernel each way);
+  * several ranks: local (mean, invstd) -> ONE flat all-gather of [mean | invstd | count]
+    per BN over RCCL -> combine -> element-wise apply; backward all-reduces
+    [sum_dy | sum_dy_xmu] (same collectives as torch's SyncBatchNorm, so numerics match);
+  * `--use_checkpoint` in the reference re-runs every block in backward (reentrant
+    checkpoint), which updates the running statistics of the BNs inside a second time with the
+    same batch statistics.  With 288 GB of HBM this build never recomputes activations; the
+    second update is replayed instead from the saved statistics, for all BNs at once with
+    multi-tensor ops, after the forward pass (`DeferredStats.flush`), which is also when the
+    reference's recompute happens.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class DeferredStats:
+    """Second running-stat update of checkpointed BNs, applied in a few multi-tensor kernels."""
+
+    def __init__(self):
+        self.rm, self.rv, self.mean, self.invstd, self.corr, self.eps, self.mom = [], [], [], [], [], [], []
+        self.calls = {}       # id(num_batches_tracked) -> [tensor, forward calls this step]
+
+    def count(self, bn, n=1):
+        e = self.calls.setdefault(id(bn.num_batches_tracked), [bn.num_batches_tracked, 0])
+        e[1] += n
+
+    def add(self, bn, mean, invstd, count):
+        self.rm.append(bn.running_mean)
+        self.rv.append(bn.running_var)
+        self.mean.append(mean)
+        self.invstd.append(invstd)
+        self.corr.append(count / max(count - 1.0, 1.0))
+        self.eps.append(bn.eps)
+        self.mom.append(bn.momentum)
+        self.count(bn)
+
+    @torch.no_grad()
+    def flush(self):
+        by_n = {}
+        for t, n in self.calls.values():
+            by_n.setdefault(n, []).append(t)
+        for n, ts in by_n.items():
+            torch._foreach_add_(ts, n)
+        self.calls = {}
+        if not self.rm:
+            return
+        var = torch._foreach_pow(self.invstd, -2.0)            # biased var + eps
+        torch._foreach_sub_(var, self.eps)
+        torch._foreach_mul_(var, self.corr)                    # unbiased
+        means = [m.to(r.dtype) for m, r in zip(self.mean, self.rm)]
+        var = [v.to(r.dtype) for v, r in zip(var, self.rv)]
+        mom = self.mom[0]
+        # a BN that ran twice this step (stem / stage 0: current and lookup frames) appears once per
+        # grad-enabled call only, so no tensor is listed twice here.
+        torch._foreach_lerp_(self.rm, means, mom)
+        torch._foreach_lerp_(self.rv, var, mom)
+        self.__init__()
+
+
+_ACTIVE_DEFERRED = None     # set by RepDepth.forward for the duration of a training forward
+
+
+def set_deferred(d):
+    global _ACTIVE_DEFERRED
+    _ACTIVE_DEFERRED = d
+
+
+class _SyncBNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, group):
+        x = x.contiguous()
+        C = x.shape[1]
+        count = x.numel() // C
+        mean, invstd = torch.batch_norm_stats(x, eps)
+        packed = torch.cat([mean, invstd, mean.new_full((1,), float(count))])
+        world = dist.get_world_size(group)
+        gathered = torch.empty(world, 2 * C + 1, device=x.device, dtype=packed.dtype)
+        dist.all_gather_into_tensor(gathered, packed, group=group)
+        mean_all, invstd_all, counts = gathered[:, :C], gathered[:, C:2 * C], gathered[:, 2 * C]
+        mean, invstd = torch.batch_norm_gather_stats_with_counts(
+            x, mean_all, invstd_all, running_mean, running_var, momentum, eps, counts)
+        ctx.save_for_backward(x, weight, mean, invstd, counts.to(torch.int32))
+        ctx.group = group
+        out = torch.batch_norm_elemt(x, weight, bias, mean, invstd, eps)
+        ctx.mark_non_differentiable(mean, invstd)
+        return out, mean, invstd
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _di):
+        x, weight, mean, invstd, counts = ctx.saved_tensors
+        dy = dy.contiguous()
+        sum_dy, sum_dy_xmu, gw, gb = torch.batch_norm_backward_reduce(
+            dy, x, mean, invstd, weight, True, True, True)
+        C = sum_dy.shape[0]
+        packed = torch.cat([sum_dy, sum_dy_xmu])
+        dist.all_reduce(packed, group=ctx.group)
+        sum_dy, sum_dy_xmu = packed[:C], packed[C:]
+        dx = torch.batch_norm_backward_elemt(dy, x, mean, invstd, weight, sum_dy, sum_dy_xmu, counts)
+        return dx, gw, gb, None, None, None, None, None
+
+
+class BatchNorm2d(nn.Module):
+    """Drop-in for nn.BatchNorm2d / nn.SyncBatchNorm (same parameters, buffers, state_dict keys)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, sync=False):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.sync = num_features, eps, momentum, sync
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.replay_update = False     # inside a segment the reference checkpoints
+
+    def extra_repr(self):
+        return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, sync={self.sync}"
+
+    def forward(self, x):
+        if not self.training:
+            return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
+                                False, self.momentum, self.eps)
+        count = x.numel() // x.shape[1]
+        multi = self.sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if multi:
+            out, mean, invstd = _SyncBNFn.apply(x, self.weight, self.bias, self.running_mean,
+                                                self.running_var, self.eps, self.momentum, None)
+            count = count * dist.get_world_size()
+        else:
+            out, mean, invstd = torch.native_batch_norm(x, self.weight, self.bias, self.running_mean,
+                                                        self.running_var, True, self.momentum, self.eps)
+        if _ACTIVE_DEFERRED is None:
+            self.num_batches_tracked += 1
+        else:
+            _ACTIVE_DEFERRED.count(self)
+            if self.replay_update and torch.is_grad_enabled():
+                _ACTIVE_DEFERRED.add(self, mean.detach(), invstd.detach(), float(count))
+        return out

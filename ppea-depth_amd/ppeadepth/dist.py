@@ -1,0 +1,131 @@
+"""Data-parallel plumbing: one process per GPU, `torch.distributed` (backend "nccl" == RCCL on ROCm,
+over xGMI inside a node; "gloo" for CPU tests).
+
+Reference behaviour (trainer.py:215-222, 350; Accelerate -> DDP): per-rank mini-batch, mean
+all-reduce of the trainable gradients (80.3 M fp32 = 321 MB at 31B; 1 306 tensors, DDP's default
+25 MB buckets), SyncBatchNorm statistics, torchmetrics min/max of the depth-bin tracker.
+
+MI355X design: xGMI is point-to-point (7 links x ~153 GB/s per GPU), so few, large collectives win.
+All trainable gradients live in ONE flat fp32 buffer (`FlatGrads`): `p.grad` of every trainable
+parameter is a view into it, autograd accumulates straight into the buffer, zeroing is one
+memset, and the exchange is `n_chunks` all-reduces of ~40-80 MB each issued on a side stream as
+soon as the backward has produced the chunk (parameters are laid out in reverse registration
+order, i.e. roughly in the order backward finishes them).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun contract)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def broadcast_module(module, src=0):
+    """Replicate parameters and buffers from `src` (what DDP does at construction)."""
+    if world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
+class FlatGrads:
+    """One contiguous gradient buffer for all trainable parameters + chunked mean all-reduce."""
+
+    def __init__(self, params, n_chunks=4, dtype=torch.float32):
+        self.params = [p for p in params if p.requires_grad]
+        # reverse registration order ~ order in which backward completes gradients
+        self.params = list(reversed(self.params))
+        device = self.params[0].device
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, device=device, dtype=dtype)
+        off = 0
+        self.offsets = []
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            self.offsets.append(off)
+            off += n
+        n_chunks = max(1, min(n_chunks, len(self.params)))
+        # chunk boundaries on parameter boundaries, ~equal bytes
+        target = self.numel / n_chunks
+        self.bounds = [0]
+        for off_i, p in zip(self.offsets, self.params):
+            if off_i + p.numel() >= target * len(self.bounds) and len(self.bounds) < n_chunks:
+                self.bounds.append(off_i + p.numel())
+        if self.bounds[-1] != self.numel:
+            self.bounds.append(self.numel)
+        self.comm_stream = torch.cuda.Stream(device) if device.type == "cuda" else None
+
+    def zero(self):
+        self.flat.zero_()
+
+    def rebind(self):
+        """Re-attach the views (an optimizer's zero_grad(set_to_none=True) would drop them)."""
+        for p, off in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+
+    def all_reduce_mean(self):
+        """Mean over ranks (DDP semantics).  Call after backward; returns when the reduced gradients
+        are visible to the current stream."""
+        w = world_size()
+        if w == 1:
+            return
+        if self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                for a, b in zip(self.bounds[:-1], self.bounds[1:]):
+                    chunk = self.flat[a:b]
+                    dist.all_reduce(chunk)
+                    chunk.mul_(1.0 / w)
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        else:
+            for a, b in zip(self.bounds[:-1], self.bounds[1:]):
+                chunk = self.flat[a:b]
+                dist.all_reduce(chunk)
+                chunk.mul_(1.0 / w)
+
+
+class TrainEngine:
+    """process_batch -> backward -> gradient exchange -> Adam step (trainer.py:345-351)."""
+
+    def __init__(self, trainer, lr=None, n_chunks=4, fused_adam=None):
+        self.trainer = trainer
+        model = trainer._module()
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.grads = FlatGrads(self.params, n_chunks=n_chunks)
+        lr = trainer.opt.learning_rate if lr is None else lr
+        on_gpu = self.params[0].is_cuda
+        if fused_adam is None:
+            fused_adam = on_gpu
+        self.optimizer = torch.optim.Adam(self.params, lr, fused=True) if fused_adam else \
+            torch.optim.Adam(self.params, lr, foreach=True)
+        self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, trainer.opt.scheduler_step_size, 0.1)
+
+    def step(self, inputs):
+        outputs, losses = self.trainer.process_batch(inputs, is_train=True)
+        self.grads.zero()
+        self.grads.rebind()
+        losses["loss"].backward()
+        self.grads.all_reduce_mean()
+        self.optimizer.step()
+        self.trainer.step += 1
+        return outputs, losses

@@ -1,0 +1,78 @@
+"""Depth decoder (reference: networks/depth_decoder_v2.py:83-245) incl. the Stage-2 decoder adapter."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..layers import ConvBlock, Conv3x3, upsample
+
+
+class Adapter(nn.Module):
+    """dec.py:19-55: Linear(C_in -> hidden) -> GELU -> Linear(hidden -> C_out), D_fc2 zero-initialised."""
+
+    def __init__(self, D_features_in, D_features_out, adpt_test=0, mlp_ratio=0.25, act_layer=nn.GELU):
+        super().__init__()
+        hidden = int((D_features_in + D_features_out) / 2 * mlp_ratio)
+        self.act = act_layer()
+        self.D_fc1 = nn.Linear(int(D_features_in), hidden)
+        self.D_fc2 = nn.Linear(hidden, int(D_features_out))
+        self.test_id = adpt_test
+        nn.init.constant_(self.D_fc2.weight, 0)
+        nn.init.constant_(self.D_fc2.bias, 0)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        t = x.flatten(2).permute(0, 2, 1)
+        t = self.D_fc2(self.act(self.D_fc1(t)))
+        return t.permute(0, 2, 1).reshape(B, -1, H, W)
+
+
+class DepthDecoderV2(nn.Module):
+    def __init__(self, num_ch_enc, scales=range(4), debug=False, num_output_channels=1, use_skips=True,
+                 dc=False, test_id=1):
+        super().__init__()
+        self.num_output_channels, self.use_skips, self.scales = num_output_channels, use_skips, scales
+        self.num_ch_enc = num_ch_enc
+        base = int(num_ch_enc[0]) // 4
+        self.ch_in_disp = np.array([base * 2 ** i for i in range(4)])
+        self.upconvs_0, self.upconvs_1 = nn.ModuleList(), nn.ModuleList()
+        for i in range(3, -1, -1):
+            ci, co = int(num_ch_enc[i]), int(num_ch_enc[i]) // 2
+            self.upconvs_0.append(ConvBlock(ci, co))
+            self.upconvs_1.append(ConvBlock(co if i == 0 else ci, co))
+        self.upconvs_0.append(ConvBlock(base * 2, base))
+        self.upconvs_1.append(ConvBlock(base, base))
+        self.disp_convs = nn.ModuleList([Conv3x3(base, num_output_channels)])
+        self.sigmoid = nn.Sigmoid()
+        self.dc, self.test_id = dc, test_id
+        if dc:
+            self.add_decoder_adapter(test_id)
+
+    def add_decoder_adapter(self, test_id, mlp_ratio=0.25):
+        """dec.py:135-169 / repdepth.py:199-203: design 1 (dec_id 1/5/6/7)."""
+        if test_id not in (1, 5, 6, 7):
+            raise NotImplementedError("decoder-adapter designs other than dec_id 1/5/6/7 are out of scope")
+        c = int(self.ch_in_disp[0])
+        self.adapter = Adapter(int(self.num_ch_enc[-1]) + int(self.num_ch_enc[0]), c, mlp_ratio=mlp_ratio)
+        self.deconv_adpt = nn.ConvTranspose2d(c, c, 3, 2, 1, output_padding=1)
+        nn.init.constant_(self.deconv_adpt.weight, 0)
+        nn.init.constant_(self.deconv_adpt.bias, 0)
+        self.dc, self.test_id = True, test_id
+
+    def forward(self, input_features):
+        self.outputs = {}
+        x = input_features[-1]
+        adpt_out = None
+        if self.dc:
+            x_up = F.interpolate(x, scale_factor=8, mode="nearest")
+            adpt_out = self.deconv_adpt(self.adapter(torch.cat([input_features[0], x_up], 1)))
+        for i in range(4):
+            x = upsample(self.upconvs_0[i](x))
+            if i < 3:
+                x = torch.cat([x, input_features[2 - i]], 1)
+            x = self.upconvs_1[i](x)
+        x = self.upconvs_1[-1](upsample(self.upconvs_0[-1](x)))
+        if self.dc:
+            x = x + F.interpolate(adpt_out, scale_factor=2)
+        self.outputs[("disp", 0)] = self.sigmoid(self.disp_convs[0](x))
+        return self.outputs

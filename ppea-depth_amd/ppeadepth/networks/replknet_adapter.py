@@ -1,0 +1,385 @@
+"""RepLKNet-31B/L backbone with PPEA adapters on gfx950 kernels.
+
+Module tree, attribute names and state_dict keys follow the reference
+(networks/replknet_adapter.py) because (a) released checkpoints load by key and (b) the freeze
+rule is a substring test on parameter names (repdepth.py:47-50).  What differs is execution:
+the large-kernel branch pair (k x k + 5 x 5 depthwise) is one fused HIP launch each way, batch
+norm is `ppeadepth.batchnorm.BatchNorm2d`, and `use_checkpoint` never recomputes activations
+(see batchnorm.py).
+"""
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops, rng
+from ..batchnorm import BatchNorm2d
+
+use_sync_bn = False
+
+
+def enable_sync_bn():
+    """replknet_adapter.py:170-174: a module-level switch that, once set, stays set."""
+    global use_sync_bn
+    use_sync_bn = True
+
+
+def get_bn(channels):
+    return BatchNorm2d(channels, sync=use_sync_bn)
+
+
+class DropPath(nn.Module):
+    """timm DropPath (stochastic depth per sample, scale_by_keep) with an injectable RNG."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = rng.bernoulli_keep(x.shape[0], keep, x)
+        if keep > 0.0:
+            mask = mask / keep
+        return x * mask
+
+    def extra_repr(self):
+        return f"drop_prob={self.drop_prob:.3f}"
+
+
+class LargeKernelDW(nn.Conv2d):
+    """Depthwise k x k conv (k > 5, stride 1, pad k//2) on the HIP kernel -- what `get_conv2d`
+    returns through the LARGE_KERNEL_CONV_IMPL hook in the reference (rka.py:157-165)."""
+
+    def __init__(self, channels, kernel_size, bias=False):
+        super().__init__(channels, channels, kernel_size, 1, kernel_size // 2, 1, channels, bias)
+
+    def forward(self, x):
+        y, _ = ops.dwconv_lk(x, self.weight, None)
+        if self.bias is not None:
+            y = y + self.bias.view(1, -1, 1, 1).to(y.dtype)
+        return y
+
+
+def get_conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias):
+    k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+    if (in_channels == out_channels == groups and k > 5 and stride == 1 and padding == k // 2
+            and dilation == 1):
+        return LargeKernelDW(in_channels, k, bias=bias)
+    return nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+
+
+def conv_bn(in_channels, out_channels, kernel_size, stride, padding, groups, dilation=1):
+    if padding is None:
+        padding = kernel_size // 2
+    seq = nn.Sequential()
+    seq.add_module("conv", get_conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation,
+                                      groups, False))
+    seq.add_module("bn", get_bn(out_channels))
+    return seq
+
+
+def conv_bn_relu(in_channels, out_channels, kernel_size, stride, padding, groups, dilation=1):
+    seq = conv_bn(in_channels, out_channels, kernel_size, stride, padding, groups, dilation)
+    seq.add_module("nonlinear", nn.ReLU())
+    return seq
+
+
+def fuse_bn(conv, bn):
+    """rka.py:199-208: fold eval-mode BN into the preceding conv's kernel and bias."""
+    std = (bn.running_var + bn.eps).sqrt()
+    t = (bn.weight / std).reshape(-1, 1, 1, 1)
+    return conv.weight * t, bn.bias - bn.running_mean * bn.weight / std
+
+
+class Adapter(nn.Module):
+    """rka.py:20-47: token-wise MLP adapter Linear -> GELU -> Linear on [B,HW,C]."""
+
+    def __init__(self, D_features, adpt_test=4, mlp_ratio=0.25, act_layer=nn.GELU):
+        super().__init__()
+        hidden = int(D_features * mlp_ratio)
+        self.feats, self.test_id = D_features, adpt_test
+        self.act = act_layer()
+        self.D_fc1 = nn.Linear(D_features, hidden)
+        self.D_fc2 = nn.Linear(hidden, D_features)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        t = x.flatten(2).permute(0, 2, 1)
+        t = self.D_fc2(self.act(self.D_fc1(t)))
+        return t.permute(0, 2, 1).reshape(B, -1, H, W)
+
+
+class B_Adapter(nn.Module):
+    """rka.py:49-109.  adpt_test == 4 (the default): Conv3x3(C -> C/4) -> GELU -> Linear(C/4 -> C)."""
+
+    def __init__(self, D_features, adpt_test=4, mlp_ratio=0.25, act_layer=nn.GELU):
+        super().__init__()
+        hidden = int(D_features * mlp_ratio)
+        self.feats, self.test_id = D_features, adpt_test
+        self.act = act_layer()
+        if adpt_test in (1, 2):
+            self.D_fc1 = nn.Linear(D_features, hidden)
+            self.D_fc2 = nn.Linear(hidden, D_features)
+        elif adpt_test == 4:
+            self.D_fc1 = nn.Conv2d(D_features, hidden, 3, 1, 1)
+            self.D_fc2 = nn.Linear(hidden, D_features)
+        else:
+            self.D_fc1 = nn.Conv2d(D_features, hidden, 3, 1, 1)
+            self.D_fc2 = nn.Conv2d(hidden, D_features, 3, 1, 1)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        if self.test_id in (1, 2):
+            x = x.flatten(2).permute(0, 2, 1)
+        h = self.D_fc1(x)
+        if self.test_id == 4:
+            h = h.flatten(2).permute(0, 2, 1)
+        h = self.D_fc2(self.act(h))
+        if self.test_id > 0:
+            h = h.permute(0, 2, 1).reshape(B, -1, H, W)
+        return h
+
+
+class ReparamLargeKernelConv(nn.Module):
+    """rka.py:210-261.  Training form: BN(DW_k(x)) + BN(DW_5(x)); both depthwise convs come out of one
+    launch that stages x in LDS once."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, groups, small_kernel,
+                 small_kernel_merged=False):
+        super().__init__()
+        self.kernel_size, self.small_kernel = kernel_size, small_kernel
+        pad = kernel_size // 2
+        if small_kernel_merged:
+            self.lkb_reparam = get_conv2d(in_channels, out_channels, kernel_size, stride, pad, 1, groups, True)
+        else:
+            self.lkb_origin = conv_bn(in_channels, out_channels, kernel_size, stride, pad, groups)
+            if small_kernel is not None:
+                assert small_kernel <= kernel_size
+                self.small_conv = conv_bn(in_channels, out_channels, small_kernel, stride, small_kernel // 2,
+                                          groups)
+
+    def forward(self, x):
+        if hasattr(self, "lkb_reparam"):
+            return self.lkb_reparam(x)
+        if not hasattr(self, "small_conv"):
+            return self.lkb_origin(x)
+        big, small = self.lkb_origin.conv, self.small_conv.conv
+        if isinstance(big, LargeKernelDW) and small.kernel_size[0] in (3, 5) and small.stride[0] == 1:
+            y_big, y_small = ops.dwconv_lk(x, big.weight, small.weight)
+            return self.lkb_origin.bn(y_big) + self.small_conv.bn(y_small)
+        return self.lkb_origin(x) + self.small_conv(x)
+
+    def get_equivalent_kernel_bias(self):
+        eq_k, eq_b = fuse_bn(self.lkb_origin.conv, self.lkb_origin.bn)
+        if hasattr(self, "small_conv"):
+            small_k, small_b = fuse_bn(self.small_conv.conv, self.small_conv.bn)
+            eq_b = eq_b + small_b
+            eq_k = eq_k + F.pad(small_k, [(self.kernel_size - self.small_kernel) // 2] * 4)
+        return eq_k, eq_b
+
+    def merge_kernel(self):
+        """rka.py:250-261 (inference-time structural re-parameterisation)."""
+        eq_k, eq_b = self.get_equivalent_kernel_bias()
+        c = self.lkb_origin.conv
+        self.lkb_reparam = get_conv2d(c.in_channels, c.out_channels, c.kernel_size, c.stride[0],
+                                      c.padding[0], c.dilation[0], c.groups, True)
+        self.lkb_reparam.weight.data = eq_k.detach()
+        self.lkb_reparam.bias.data = eq_b.detach()
+        del self.lkb_origin
+        if hasattr(self, "small_conv"):
+            del self.small_conv
+
+
+class ConvFFN(nn.Module):
+    """rka.py:264-289."""
+
+    def __init__(self, in_channels, internal_channels, out_channels, drop_path, gamma=1.0, adpt_test=0,
+                 ratio=0.25):
+        super().__init__()
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.preffn_bn = get_bn(in_channels)
+        self.pw1 = conv_bn(in_channels, internal_channels, 1, 1, 0, 1)
+        self.pw2 = conv_bn(internal_channels, out_channels, 1, 1, 0, 1)
+        self.nonlinear = nn.GELU()
+        if adpt_test >= 0:
+            self.mlp_adapter = Adapter(in_channels, adpt_test, 0.5 if adpt_test == 2 else 0.25)
+        self.gamma, self.test_id = gamma, adpt_test
+
+    def forward(self, x):
+        out = self.preffn_bn(x)
+        adpt = self.mlp_adapter(out) if self.test_id >= 0 else None
+        out = self.pw2(self.nonlinear(self.pw1(out)))
+        y = x + self.drop_path(out)
+        return y if adpt is None else y + self.gamma * adpt
+
+
+class RepLKBlock(nn.Module):
+    """rka.py:292-326."""
+
+    def __init__(self, in_channels, dw_channels, block_lk_size, small_kernel, drop_path, gamma=1.0,
+                 small_kernel_merged=False, adpt_test=0, ratio=0.25):
+        super().__init__()
+        self.pw1 = conv_bn_relu(in_channels, dw_channels, 1, 1, 0, 1)
+        self.pw2 = conv_bn(dw_channels, in_channels, 1, 1, 0, 1)
+        self.large_kernel = ReparamLargeKernelConv(dw_channels, dw_channels, block_lk_size, 1, dw_channels,
+                                                   small_kernel, small_kernel_merged)
+        self.lk_nonlinear = nn.ReLU()
+        self.prelkb_bn = get_bn(in_channels)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        if adpt_test >= 0:
+            self.adapter = B_Adapter(in_channels, adpt_test, ratio)
+        self.gamma, self.test_id = gamma, adpt_test
+
+    def forward(self, x):
+        out = self.prelkb_bn(x)
+        adpt = self.adapter(out) if self.test_id >= 0 else None
+        out = self.pw2(self.lk_nonlinear(self.large_kernel(self.pw1(out))))
+        y = x + self.drop_path(out)
+        return y if adpt is None else y + self.gamma * adpt
+
+
+class RepLKNetStage(nn.Module):
+    """rka.py:329-369."""
+
+    def __init__(self, channels, num_blocks, stage_lk_size, drop_path, small_kernel, g_blk=1.0, g_ffn=1.0,
+                 dw_ratio=1, ffn_ratio=4, use_checkpoint=False, small_kernel_merged=False,
+                 norm_intermediate_features=False, adpt_test=0, ratio=0.25):
+        super().__init__()
+        self.use_checkpoint = use_checkpoint
+        blks = []
+        for i in range(num_blocks):
+            a_r, a_c = adpt_test, adpt_test
+            if adpt_test == 5:
+                a_r, a_c = -1, 1
+            if adpt_test == 6:
+                a_r, a_c = 4, -1
+            dp = drop_path[i] if isinstance(drop_path, list) else drop_path
+            blks.append(RepLKBlock(channels, int(channels * dw_ratio), stage_lk_size, small_kernel, dp, g_blk,
+                                   small_kernel_merged, a_r, ratio))
+            blks.append(ConvFFN(channels, int(channels * ffn_ratio), channels, dp, g_ffn, a_c, ratio))
+        self.blocks = nn.ModuleList(blks)
+        self.norm = get_bn(channels) if norm_intermediate_features else nn.Identity()
+        if use_checkpoint:
+            _mark_replay(self.blocks)
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = blk(x)
+        return x
+
+
+def _mark_replay(module):
+    """BNs inside a segment the reference wraps in checkpoint.checkpoint (rka.py:364-368, 515-519)."""
+    for m in module.modules():
+        if isinstance(m, BatchNorm2d):
+            m.replay_update = True
+
+
+class RepLKNetAdapter(nn.Module):
+    """rka.py:381-628."""
+
+    def __init__(self, large_kernel_sizes, layers, channels, drop_path_rate, small_kernel, dw_ratio=1,
+                 ffn_ratio=4, in_channels=3, num_classes=1000, out_indices=None, use_checkpoint=False,
+                 small_kernel_merged=False, use_sync_bn=True, norm_intermediate_features=False,
+                 pretrained=None, g_blk=1, g_ffn=1, trans_adpt=False, input_adpt=False, adpt_test=0,
+                 ratio=0.25, num_input_images=1):
+        super().__init__()
+        if num_classes is not None and out_indices is not None:
+            raise ValueError("cannot specify both num_classes (for pretraining) and out_indices")
+        if trans_adpt or input_adpt:
+            raise NotImplementedError("--trans / --input adapters are outside the hot-path scope (SURVEY 2)")
+        self.out_indices = out_indices
+        if use_sync_bn:
+            enable_sync_bn()
+        self.channels = channels
+        self.use_checkpoint = use_checkpoint
+        self.num_stages = len(layers)
+        self.num_input_images = num_input_images
+        self.trans_adpt, self.input_adpt = False, False
+        bw = channels[0]
+        self.stem = nn.ModuleList([
+            conv_bn_relu(in_channels * num_input_images, bw, 3, 2, 1, 1),
+            conv_bn_relu(bw, bw, 3, 1, 1, bw),
+            conv_bn_relu(bw, bw, 1, 1, 0, 1),
+            conv_bn_relu(bw, bw, 3, 2, 1, bw)])
+        if use_checkpoint:
+            _mark_replay(self.stem[1:])
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(layers))]
+        self.stages = nn.ModuleList()
+        self.transitions = nn.ModuleList()
+        for s in range(self.num_stages):
+            self.stages.append(RepLKNetStage(
+                channels[s], layers[s], large_kernel_sizes[s], dpr[sum(layers[:s]):sum(layers[:s + 1])],
+                small_kernel, g_blk, g_ffn, dw_ratio, ffn_ratio, use_checkpoint, small_kernel_merged,
+                norm_intermediate_features, adpt_test, ratio))
+            if s < len(layers) - 1:
+                self.transitions.append(nn.Sequential(
+                    conv_bn_relu(channels[s], channels[s + 1], 1, 1, 0, 1),
+                    conv_bn_relu(channels[s + 1], channels[s + 1], 3, 2, 1, channels[s + 1])))
+        if num_classes is not None:
+            self.norm = get_bn(channels[-1])
+            self.avgpool = nn.AdaptiveAvgPool2d(1)
+            self.head = nn.Linear(channels[-1], num_classes)
+        if pretrained:
+            self.load_pretrained(pretrained)
+        # adapter output projections start at zero (rka.py:482-493)
+        for n, m in self.named_modules():
+            if "adapter" in n and n.endswith("D_fc2") and isinstance(m, (nn.Linear, nn.Conv2d)):
+                nn.init.constant_(m.weight, 0)
+                nn.init.constant_(m.bias, 0)
+
+    def load_pretrained(self, path):
+        if not os.path.exists(path):
+            print(f"[ppeadepth] pretrained backbone {path} not found: keeping random initialisation")
+            return
+        weights = torch.load(path, map_location="cpu")
+        for key in ("model", "state_dict"):
+            if isinstance(weights, dict) and key in weights:
+                weights = weights[key]
+        if self.num_input_images == 2 and "stem.0.conv.weight" in weights:
+            weights["stem.0.conv.weight"] = torch.cat([weights["stem.0.conv.weight"]] * 2, 1) / 2
+        self.load_state_dict(weights, strict=False)
+
+    def stem_forward(self, x):
+        for layer in self.stem:
+            x = layer(x)
+        return x
+
+    def forward_features(self, x):
+        x = self.stem_forward(x)
+        outs = []
+        for s in range(self.num_stages):
+            x = self.stages[s](x)
+            if self.out_indices is not None and s in self.out_indices:
+                outs.append(self.stages[s].norm(x))
+            if s < self.num_stages - 1:
+                x = self.transitions[s](x)
+        return x if self.out_indices is None else outs
+
+    def forward(self, x):
+        return self.forward_features(x)
+
+    def structural_reparam(self):
+        for m in self.modules():
+            if hasattr(m, "merge_kernel"):
+                m.merge_kernel()
+
+
+def _factory(channels):
+    def create(drop_path_rate=0.3, num_classes=1000, num_input_images=1, out_indices=(0, 1, 2, 3),
+               use_checkpoint=True, small_kernel_merged=False, pretrained=None, use_sync_bn=True, g_blk=1.0,
+               g_ffn=1.0, ratio=0.25, trans_adpt=False, input_adpt=False, adpt_test=0):
+        return RepLKNetAdapter([31, 29, 27, 13], [2, 2, 18, 2], channels, drop_path_rate, 5,
+                               num_classes=num_classes, out_indices=out_indices,
+                               use_checkpoint=use_checkpoint, small_kernel_merged=small_kernel_merged,
+                               use_sync_bn=use_sync_bn, pretrained=pretrained, g_blk=g_blk, g_ffn=g_ffn,
+                               trans_adpt=trans_adpt, input_adpt=input_adpt, adpt_test=adpt_test, ratio=ratio,
+                               num_input_images=num_input_images)
+    return create
+
+
+create_RepLKNet31B_Adapter = _factory([128, 256, 512, 1024])     # rka.py:630-633
+create_RepLKNet31L_Adapter = _factory([192, 384, 768, 1536])     # rka.py:635-638
