@@ -141,6 +141,7 @@ class RefRepDepth:
             look = self._stage(self._stem(lookup_imgs.flatten(0, 1), p), p, 0)
             look = look.reshape(B, Fr, *look.shape[1:])
             cost, missing = R.cost_volume(cur, look, poses, K, inv_K, bins)
+            self.debug = {"cur": cur.detach(), "look": look, "cost_filled": cost, "bins": bins, "poses": poses}
             conf, idx, lowest, cost = R.cost_volume_reduce(cost, missing, bins)
         x = F.relu(F.conv2d(torch.cat([cur, cost], 1), sd["encoder.reduce_conv.0.weight"],
                             sd["encoder.reduce_conv.0.bias"], padding=1))

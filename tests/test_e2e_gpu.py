@@ -62,8 +62,11 @@ def _check(g, model, tr, inputs, outputs, losses, stride):
         if key == "augmentation_mask":
             assert torch.equal(mine, v)
         elif key in exact_like:
-            # derived from the cost-volume argmin: identical except at near-tie pixels
-            bad = (mine != v).float().mean().item()
+            # derived from the cost-volume argmin (lowest_cost = 1 / bins[argmin], bins from exp/log):
+            # equal to float rounding except at pixels where the reference's two best bins are tied to
+            # ~1e-5 relative (tools/debug_e2e.py prints them); their share is bounded here, the
+            # kernel itself is bit-exact on identical inputs (test_kernels_gpu.test_cost_volume_golden).
+            bad = ((mine - v).abs() > 1e-5 * v.abs().clamp_min(1e-6)).float().mean().item()
             assert bad < 5e-3, (k, bad)
         elif key == "consistency_target/0":
             bad = ((mine - v).abs() > 1e-3 * v.abs().max()).float().mean().item()
