@@ -96,11 +96,13 @@ int ppea_ssim_l1_bwd_f32(const float* pred, const float* target, const float* d_
 
 /* ------------------------------------------------------------------------------------------
  * A23  get_smooth_loss (layers.py:210-223).  disp [B,1,H,W], img [B,C,H,W].
- *      sums[0] += sum |dx disp| e^{-mean_c|dx img|}, sums[1] += same for dy (ACCUMULATED;
- *      caller zero-fills and divides by the element counts B*H*(W-1), B*(H-1)*W).
+ *      partials [ppea_smooth_num_partials()][2]: per-workgroup partial sums (deterministic, no
+ *      atomics); column 0 = sum |dx disp| e^{-mean_c|dx img|}, column 1 = same for dy.  The caller
+ *      adds the rows and divides by the element counts B*H*(W-1) and B*(H-1)*W.
  *      bwd: d_disp = gx * d(sum_x)/d(disp) + gy * d(sum_y)/d(disp) with scalar weights.
  * ---------------------------------------------------------------------------------------- */
-int ppea_smooth_fwd_f32(const float* disp, const float* img, float* sums,
+int ppea_smooth_num_partials(void);
+int ppea_smooth_fwd_f32(const float* disp, const float* img, float* partials,
                         int B, int C, int H, int W, void* stream);
 int ppea_smooth_bwd_f32(const float* disp, const float* img, float gx, float gy, float* d_disp,
                         int B, int C, int H, int W, void* stream);

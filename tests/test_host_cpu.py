@@ -1,0 +1,203 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every declared symbol, the product
+refuses to run without a HIP device, host logic (model structure, freeze rule, BN bookkeeping,
+depth-bin tracker, flat-gradient data parallelism over gloo with world_size 2)."""
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, ROOT, rel_err
+
+
+def test_abi_exports_every_declared_symbol():
+    from ppeadepth import _abi
+    header = open(os.path.join(ROOT, "include", "ppea_depth.h")).read()
+    declared = set(re.findall(r"^int\s+(ppea_\w+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_abi.SIGNATURES), declared ^ set(_abi.SIGNATURES)
+    for name in declared:
+        assert hasattr(_abi.lib, name), name
+    assert _abi.lib.ppea_abi_version() == _abi.ABI_VERSION
+    # argument counts in the header match the ctypes signatures
+    for m in re.finditer(r"^int\s+(ppea_\w+)\s*\(([^;]*?)\);", header, flags=re.M | re.S):
+        name, args = m.group(1), m.group(2).strip()
+        n = 0 if args in ("void", "") else len([a for a in args.split(",") if a.strip()])
+        assert n == len(_abi.SIGNATURES[name]), (name, n, len(_abi.SIGNATURES[name]))
+
+
+def test_product_fails_loudly_without_hip_device():
+    from ppeadepth import _abi, ops
+    x = torch.randn(1, 2, 8, 8)
+    w = torch.randn(2, 1, 7, 7)
+    with pytest.raises(_abi.PpeaKernelError):
+        ops.dwconv_lk(x, w, None)
+    with pytest.raises(_abi.PpeaKernelError):
+        ops.ssim_l1(torch.rand(1, 3, 8, 8), torch.rand(1, 3, 8, 8))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "ppea-depth_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(d, f)).read()
+                assert "oracle" not in src or f == "README.md", os.path.join(d, f)
+
+
+@pytest.mark.parametrize("size", ["b", "l"])
+def test_model_state_dict_and_freeze_rule_match_reference(size):
+    from ppeadepth import networks, options
+    z = np.load(os.path.join(GOLDEN, "state_spec.npz"))
+    names = [str(n) for n in z[f"{size}:names"]]
+    shapes = {n: tuple(int(d) for d in str(s).split(";") if d) for n, s in zip(names, z[f"{size}:shapes"])}
+    trainable = dict(zip(names, z[f"{size}:trainable"]))
+    model = networks.RepDepth(options.default_options(rep_size=size))
+    sd = model.state_dict()
+    assert list(sd.keys()) == names or set(sd.keys()) == set(names)
+    for n, v in sd.items():
+        assert tuple(v.shape) == shapes[n], n
+    for n, p in model.named_parameters():
+        assert p.requires_grad == bool(trainable[n]), n
+    # adapter output projections start at zero (replknet_adapter.py:482-493)
+    assert float(sd["encoder.replk.stages.0.blocks.0.adapter.D_fc2.weight"].abs().max()) == 0.0
+    assert float(sd["mono_encoder.stages.2.blocks.5.mlp_adapter.D_fc2.bias"].abs().max()) == 0.0
+    # drop-path schedule: linspace(0, 0.3, 24) per block pair, first pair identity
+    from ppeadepth.networks.replknet_adapter import DropPath
+    blocks = [b for st in model.mono_encoder.stages for b in st.blocks]
+    rates = [b.drop_path.drop_prob if isinstance(b.drop_path, DropPath) else 0.0 for b in blocks]
+    want = [x.item() for x in torch.linspace(0, 0.3, 24)]
+    assert rates == [want[i // 2] for i in range(48)]
+
+
+def test_decoder_adapter_stage2_keys():
+    """--dc: depth.adapter.D_fc{1,2}, depth.deconv_adpt (zero-init), decoders frozen except adapters
+    (repdepth.py:175-262; hidden = int((1152 + 32) / 2 * 0.25) = 148)."""
+    from ppeadepth import networks, options
+    model = networks.RepDepth(options.default_options(rep_size="b"))
+    model.dc_ft_init()
+    sd = model.state_dict()
+    assert tuple(sd["depth.adapter.D_fc1.weight"].shape) == (148, 1152)
+    assert tuple(sd["mono_depth.deconv_adpt.weight"].shape) == (32, 32, 3, 3)
+    assert float(sd["depth.deconv_adpt.weight"].abs().max()) == 0.0
+    for n, p in model.depth.named_parameters():
+        assert p.requires_grad == ("adpt" in n or "adapter" in n), n
+
+
+def test_bn_replay_matches_two_sequential_updates():
+    """use_checkpoint semantics without recompute: replayed second running-stat update."""
+    from ppeadepth.batchnorm import BatchNorm2d, DeferredStats, set_deferred
+    torch.manual_seed(0)
+    x = torch.randn(4, 6, 5, 7) * 2 + 1
+    bn = BatchNorm2d(6).train()
+    bn.replay_update = True
+    ref = torch.nn.BatchNorm2d(6).train()
+    book = DeferredStats()
+    set_deferred(book)
+    y = bn(x)
+    set_deferred(None)
+    book.flush()
+    y_ref = ref(x)
+    ref(x)                                    # the reentrant-checkpoint recompute
+    assert rel_err(y, y_ref) < 1e-6
+    assert rel_err(bn.running_mean, ref.running_mean) < 1e-6
+    assert rel_err(bn.running_var, ref.running_var) < 1e-6
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+    with torch.no_grad():                     # no_grad pass (lookup frames): single update
+        book = DeferredStats()
+        set_deferred(book)
+        bn(x)
+        set_deferred(None)
+        book.flush()
+        ref(x)
+    assert rel_err(bn.running_var, ref.running_var) < 1e-6
+    assert int(bn.num_batches_tracked) == 3
+
+
+def test_depth_bins_tracker(golden):
+    from ppeadepth.trainer import DepthBins
+    g = golden("depth_bins")
+    tr = DepthBins(0.1)
+    for i in range(g["depths"].shape[0]):
+        tr.update(g["depths"][i])
+        mn, mx = tr.compute()
+        assert rel_err(mn, g["mins"][i]) < 1e-6 and rel_err(mx, g["maxs"][i]) < 1e-6
+
+
+def test_geometry_helpers_match_reference_golden(golden):
+    from ppeadepth import layers
+    g = golden("layers_geometry")
+    sd, depth = layers.disp_to_depth(g["disp"], 0.1, 100.0)
+    assert rel_err(depth, g["depth"]) < 1e-6
+    for inv, key in ((False, "T_fwd"), (True, "T_inv")):
+        T = layers.transformation_from_parameters(g["axisangle"], g["translation"], inv)
+        assert rel_err(T, g[key]) < 1e-6
+    B, _, H, W = g["depth"].shape
+    pts = layers.BackprojectDepth(B, H, W)(g["depth"], g["inv_K"])
+    assert rel_err(pts, g["points"]) < 1e-6
+    grid = layers.Project3D(B, H, W)(pts, g["K"], g["T_inv"])
+    assert (grid - g["grid"]).abs().max() < 1e-5
+
+
+def test_depth_bins_log_match_reference(golden):
+    from ppeadepth.networks import RepLKMatchingAdapter
+    g = golden("cost_volume")
+    me = types.SimpleNamespace(num_depth_bins=96, depth_binning="log")
+    bins = RepLKMatchingAdapter.compute_depth_bins(me, g["min_depth"], g["max_depth"])
+    assert rel_err(bins, g["bins"]) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from ppeadepth import dist as pdist
+    from ppeadepth.trainer import DepthBins
+    pdist.init_distributed("gloo")
+    torch.manual_seed(0)                                 # same init everywhere
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4),
+                                torch.nn.Linear(4, 3))
+    model[3].weight.requires_grad = False                # a frozen tensor stays out of the flat buffer
+    pdist.broadcast_module(model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    flat = pdist.FlatGrads(params, n_chunks=3)
+    torch.manual_seed(100 + rank)                        # different data per rank
+    x = torch.randn(5, 8)
+    flat.zero()
+    model(x).pow(2).sum().backward()
+    local = [p.grad.clone() for p in params]
+    flat.all_reduce_mean()
+    gathered = [torch.zeros_like(torch.cat([g.reshape(-1) for g in local])) for _ in range(world)]
+    dist.all_gather(gathered, torch.cat([g.reshape(-1) for g in local]))
+    want = sum(gathered) / world
+    got = torch.cat([p.grad.reshape(-1) for p in params])
+    ok_grad = torch.allclose(got, want, atol=1e-6)
+    ok_view = all(p.grad.data_ptr() >= flat.flat.data_ptr() for p in params) and model[3].weight.grad is None
+    # depth-bin tracker: min over ranks of min_depth, max over ranks of max_depth (torchmetrics dist_reduce_fx)
+    tr = DepthBins(0.1)
+    tr.min_depth = torch.tensor(0.2 + rank)
+    tr.max_depth = torch.tensor(5.0 + rank)
+    mn, mx = tr.compute()
+    ok_bins = abs(float(mn) - 0.2) < 1e-6 and abs(float(mx) - (5.0 + world - 1)) < 1e-6
+    q.put((rank, ok_grad, ok_view, ok_bins, len(flat.bounds) - 1))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert len(res) == 2
+    for rank, ok_grad, ok_view, ok_bins, chunks in res:
+        assert ok_grad and ok_view and ok_bins, (rank, ok_grad, ok_view, ok_bins)
+        assert chunks >= 2
