@@ -1,0 +1,334 @@
+// Large-kernel depthwise convolution on the matrix cores (bf16 in / fp32 accumulate), gfx950.
+//
+// Banded-Toeplitz formulation (im2col-free).  For one channel and one filter row ky
+//     out[y][x] += sum_j in[y + ky - P][j] * T_ky[j][x],      T_ky[j][x] = w[ky][j - x + P]
+// i.e. a GEMM  (rows y) x (cols x)  with the contraction over input columns j.  Per 16x16
+// output tile only j in [x0 - P, x0 + 15 + P] contributes, which fits NS chunks of 32
+// columns, so a tile costs K * NS `v_mfma_f32_16x16x32_bf16` (48 % of their MACs are useful at
+// K = 31 -- still ~8x the fp32 vector peak).
+//
+//   A operand = 16 input rows x 32 input columns: one `ds_read_b128` per lane from the LDS image
+//               of the plane (lane l: row l&15, columns 8*(l>>4)..+7), immediate offsets for
+//               (ky, chunk); row stride = 288 B (== 32 mod 256 -> conflict-free b128 reads);
+//   B operand = Toeplitz fragment of filter row ky; depends on (ky, chunk, lane) only, so ALL
+//               K*NS fragments of the wave's channel live in registers for the whole kernel
+//               (K = 31: 248 VGPRs; one wave per SIMD owns the 512-entry file) -- weights are
+//               read once per workgroup, every MFMA's B comes from registers;
+//   C tile    = 4 fp32 per lane, chained over ky (dependent 16x16x32 MFMAs issue back to back).
+//
+// A wave owns one work item = (group of G stacked planes of one channel with G*H <= 48 rows, or a
+// 48-row band of one plane) x (segment of NSEG column tiles).  The four waves of a workgroup share
+// the channel and its padded filter image in LDS.  The 5x5 re-param branch (fwd: second output;
+// dgrad: second input, same accumulator) costs 5 more MFMAs per tile.
+// Replaces nn.Conv2d(groups=C) at networks/replknet_adapter.py:225-239 under bf16 autocast.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int WPAD = 96;             // padded filter row: taps at [32, 32+K)
+constexpr int WAVES = 4;
+constexpr int LDS_LIMIT = 160 * 1024;
+
+// LDS row stride in bytes for WL staged columns: smallest S >= 2*WL with S/32 odd, so that the 16
+// rows x 4 k-groups of a ds_read_b128 fall on distinct 16-byte slots of the 256-byte bank row.
+constexpr int lds_stride_bytes(int wl) {
+    int s = (2 * wl + 31) / 32;
+    if ((s & 1) == 0) ++s;
+    return 32 * s;
+}
+
+template <int K>
+struct Geo {
+    static constexpr int P = K / 2;
+    static constexpr int NS = (16 + 2 * P <= 32) ? 1 : 2;      // 32-column chunks per tile
+    static constexpr int JOFF = (NS == 1) ? 8 : 16;            // first chunk starts at x0 - JOFF
+    static_assert(JOFF >= P && 32 * NS - JOFF >= 16 + P, "band does not fit the chunks");
+};
+
+template <int K, int NSEG>
+struct Seg {
+    static constexpr int WL = 16 * (NSEG - 1) + 32 * Geo<K>::NS;     // staged columns per item
+    static constexpr int STRIDE = lds_stride_bytes(WL);
+};
+
+// B fragment for (filter row `wrow` of the padded LDS image, chunk s): taps t0..t0+7 with
+// t0 = 32*s + 8*(lane>>4) - (lane&15) + (P - JOFF); two LDS copies (even / odd alignment) keep the
+// reads 4-byte aligned.
+template <int P, int JOFF>
+__device__ __forceinline__ bf16x8 load_bfrag(const uint16_t* wrow_even, const uint16_t* wrow_odd, int s,
+                                             int lane) {
+    const int t0 = 32 * s + 8 * (lane >> 4) - (lane & 15) + (P - JOFF);
+    const int i0 = t0 + 32;                                   // index into the padded row, in [0, WPAD-8]
+    const uint16_t* src = (i0 & 1) ? (wrow_odd + (i0 - 1)) : (wrow_even + i0);
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(src);
+    uint4 v;
+    v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// Stage the padded filter image of channel c (flipped for dgrad): wimg[copy][ky][WPAD].
+template <int K>
+__device__ __forceinline__ void stage_filter(uint16_t* wimg, const float* __restrict__ w, bool flip, int tid,
+                                             int nthreads) {
+    for (int i = tid; i < 2 * K * WPAD; i += nthreads) {
+        const int copy = i / (K * WPAD);
+        const int r = i - copy * K * WPAD;
+        const int ky = r / WPAD, col = r - ky * WPAD;
+        const int t = col + copy - 32;                        // odd copy is shifted left by one
+        float v = 0.f;
+        if (t >= 0 && t < K) v = flip ? w[(K - 1 - ky) * K + (K - 1 - t)] : w[ky * K + t];
+        wimg[i] = f32_to_bf16(v);
+    }
+}
+
+struct Item {
+    int n0;        // first image of the group
+    int G;         // images stacked
+    int y0;        // first output row (band) inside each image
+    int rows;      // output rows per image in this item
+    int x0;        // first output column of the segment
+};
+
+// Stage G planes' rows [y0 - P, y0 + rows + P) x cols [x0 - JOFF, x0 - JOFF + WL) into LDS (bf16, zeros outside).
+template <int K, int NSEG>
+__device__ __forceinline__ void stage_planes(uint8_t* tile, const uint16_t* __restrict__ src, const Item& it,
+                                             int C, int c, int H, int W, int lane) {
+    using GE = Geo<K>;
+    constexpr int WL = Seg<K, NSEG>::WL;
+    constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
+    const int rows_l = it.rows + K - 1;                        // LDS rows per image
+    const int total = it.G * rows_l * (WL / 8);
+    const bool vec_ok = ((W & 7) == 0);
+    for (int i = lane; i < total; i += WAVE) {
+        const int cg = i % (WL / 8);
+        const int rr = i / (WL / 8);
+        const int g = rr / rows_l, r = rr - g * rows_l;
+        const int gy = it.y0 - GE::P + r;
+        const int gx = it.x0 - GE::JOFF + cg * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (gy >= 0 && gy < H) {
+            const uint16_t* rowp = src + (((long)(it.n0 + g) * C + c) * H + gy) * W;
+            if (vec_ok && gx >= 0 && gx + 8 <= W) {
+                v = *reinterpret_cast<const uint4*>(rowp + gx);
+            } else {
+                uint16_t e[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[k] = (gx + k >= 0 && gx + k < W) ? rowp[gx + k] : (uint16_t)0;
+                v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
+                v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+            }
+        }
+        *reinterpret_cast<uint4*>(tile + (long)rr * STRIDE_B + cg * 16) = v;
+    }
+}
+
+// acc += sum over filter rows of A(rows, chunk) * B(ky, chunk) for one 16x16 tile.
+// `abase` = LDS byte address of (first input row of this lane's output row, first chunk column of
+// the tile) + 16 * (lane >> 4); ROW0 = extra row offset (small kernel inside the big halo).
+template <int KK, int NS, int ROW0, int STRIDE_B>
+__device__ __forceinline__ void tile_mac(f32x4& acc, const uint8_t* abase, const bf16x8 (&bf)[KK][NS]) {
+#pragma unroll
+    for (int ky = 0; ky < KK; ++ky) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const uint4 av = *reinterpret_cast<const uint4*>(abase + (ky + ROW0) * STRIDE_B + s * 64);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), bf[ky][s], acc, 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void store_tile(uint16_t* __restrict__ dst, const f32x4& acc, const Item& it, int C,
+                                           int c, int H, int W, int mt, int xt, int lane) {
+    const int col = xt + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = mt * 16 + 4 * (lane >> 4) + i;           // stacked output row
+        const int g = m / it.rows, y = it.y0 + (m - g * it.rows);
+        if (g < it.G && y < H && col < W)
+            dst[(((long)(it.n0 + g) * C + c) * H + y) * W + col] = f32_to_bf16(acc[i]);
+    }
+}
+
+// MODE 0: fwd  (in0 = x; out0 = y_big, out1 = y_small if KS)
+// MODE 1: dgrad (in0 = dy_big, in1 = dy_small if KS; out0 = dx), filters flipped
+template <int K, int KS, int MODE, int NSEG>
+__global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
+    const uint16_t* __restrict__ in0, const uint16_t* __restrict__ in1, const float* __restrict__ w_big,
+    const float* __restrict__ w_small, uint16_t* __restrict__ out0, uint16_t* __restrict__ out1, int N, int C,
+    int H, int W, int G, int band, int bands, int segs, int items_per_channel, int tile_bytes) {
+    using GE = Geo<K>;
+    using GS = Geo<(KS > 0 ? KS : 5)>;
+    constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
+    constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
+    constexpr int FILT_BYTES = ((2 * K * WPAD + 2 * KS * WPAD) * 2 + 15) & ~15;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // layout: [filter big: 2*K*WPAD u16][filter small: 2*KS*WPAD u16][WAVES x NT_IN input tiles]
+    uint16_t* wimg_b = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* wimg_s = wimg_b + 2 * K * WPAD;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int chunks_per_channel = (items_per_channel + WAVES - 1) / WAVES;
+    const int c = blockIdx.x / chunks_per_channel;
+    const int item_id = (blockIdx.x - c * chunks_per_channel) * WAVES + wave;
+    const bool active = item_id < items_per_channel;
+
+    stage_filter<K>(wimg_b, w_big + (long)c * K * K, MODE == 1, threadIdx.x, 64 * WAVES);
+    if constexpr (KS > 0) stage_filter<KS>(wimg_s, w_small + (long)c * KS * KS, MODE == 1, threadIdx.x, 64 * WAVES);
+
+    Item it;                                 // item = (plane group or row band, column segment)
+    {
+        const int id = active ? item_id : 0;
+        const int seg = id % segs;
+        const int gb = id / segs;
+        it.x0 = seg * 16 * NSEG;
+        if (G > 1) {                         // G small planes stacked along M, whole height
+            it.n0 = gb * G;
+            it.G = min(G, N - it.n0);
+            it.y0 = 0;
+            it.rows = H;
+        } else {                             // one plane, bands of `band` rows
+            it.n0 = gb / bands;
+            it.G = 1;
+            it.y0 = (gb - it.n0 * bands) * band;
+            it.rows = min(band, H - it.y0);
+        }
+    }
+    const int rows_l = it.rows + K - 1;      // LDS rows per stacked image (with halo)
+    uint8_t* tile0 = smem + FILT_BYTES + (long)wave * NT_IN * tile_bytes;
+    uint8_t* tile1 = tile0 + tile_bytes;
+
+    if (active) {
+        stage_planes<K, NSEG>(tile0, in0, it, C, c, H, W, lane);
+        if constexpr (NT_IN == 2) stage_planes<K, NSEG>(tile1, in1, it, C, c, H, W, lane);
+    }
+    __syncthreads();
+
+    // Toeplitz fragments of the whole filter: registers for the rest of the kernel
+    bf16x8 bf_big[K][GE::NS];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int s = 0; s < GE::NS; ++s)
+            bf_big[ky][s] = load_bfrag<GE::P, GE::JOFF>(wimg_b + ky * WPAD, wimg_b + (K + ky) * WPAD, s, lane);
+    bf16x8 bf_small[(KS > 0 ? KS : 1)][1];
+    if constexpr (KS > 0) {
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+            bf_small[ky][0] = load_bfrag<GS::P, GS::JOFF>(wimg_s + ky * WPAD, wimg_s + (KS + ky) * WPAD, 0, lane);
+    }
+    if (!active) return;
+
+    const int ntiles_x = min(NSEG, (W - it.x0 + 15) / 16);
+    const int mrows = it.G * it.rows;
+    const int ntiles_m = (mrows + 15) / 16;
+    constexpr int SM_ROW0 = GE::P - GS::P;                  // small-kernel rows inside the big halo
+    constexpr int SM_COLB = (GE::JOFF - GS::JOFF) * 2;      // byte offset of its first chunk
+
+    for (int mt = 0; mt < ntiles_m; ++mt) {
+        // this lane's output row -> first LDS row of its window (clamped for padding rows)
+        const int m = min(mt * 16 + (lane & 15), mrows - 1);
+        const int g = m / it.rows, y = m - g * it.rows;
+        const long aoff = (long)(g * rows_l + y) * STRIDE_B + 16 * (lane >> 4);
+        const uint8_t* arow0 = tile0 + aoff;
+        const uint8_t* arow1 = tile1 + aoff;
+        for (int nt = 0; nt < ntiles_x; ++nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            tile_mac<K, GE::NS, 0, STRIDE_B>(acc, arow0 + nt * 32, bf_big);
+            if constexpr (MODE == 0) {
+                store_tile(out0, acc, it, C, c, H, W, mt, it.x0 + nt * 16, lane);
+                if constexpr (KS > 0) {
+                    f32x4 acs = {0.f, 0.f, 0.f, 0.f};
+                    tile_mac<KS, 1, SM_ROW0, STRIDE_B>(acs, arow0 + nt * 32 + SM_COLB, bf_small);
+                    store_tile(out1, acs, it, C, c, H, W, mt, it.x0 + nt * 16, lane);
+                }
+            } else {
+                if constexpr (KS > 0) tile_mac<KS, 1, SM_ROW0, STRIDE_B>(acc, arow1 + nt * 32 + SM_COLB, bf_small);
+                store_tile(out0, acc, it, C, c, H, W, mt, it.x0 + nt * 16, lane);
+            }
+        }
+    }
+}
+
+template <int K, int KS, int MODE, int NSEG>
+int launch(const uint16_t* in0, const uint16_t* in1, const float* wb, const float* ws, uint16_t* o0,
+           uint16_t* o1, int N, int C, int H, int W, hipStream_t st) {
+    constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
+    constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
+    constexpr int FILT_BYTES = ((2 * K * WPAD + 2 * KS * WPAD) * 2 + 15) & ~15;
+    // largest band / stacking that fits the 160 KB of LDS with four waves per workgroup
+    int band = 0, G = 1, tile_bytes = 0;
+    for (int cand : {48, 32, 16}) {
+        int g = (H < cand) ? (cand / H < N ? cand / H : N) : 1;
+        if (g < 1) g = 1;
+        for (; g >= 1; --g) {
+            const int rows = (g > 1) ? g * (H + K - 1) : ((H < cand ? H : cand) + K - 1);
+            const int tb = (rows * STRIDE_B + 15) & ~15;
+            if (FILT_BYTES + WAVES * NT_IN * tb <= LDS_LIMIT) { band = cand; G = g; tile_bytes = tb; break; }
+        }
+        if (band) break;
+    }
+    if (!band) return PPEA_ERR_UNSUPPORTED;
+    const int bands = (G > 1) ? 1 : (H + band - 1) / band;
+    const int segs = (W + 16 * NSEG - 1) / (16 * NSEG);
+    const int groups = (G > 1) ? (N + G - 1) / G : N * bands;
+    const int items_per_channel = groups * segs;
+    const int chunks = (items_per_channel + WAVES - 1) / WAVES;
+    const size_t lds = (size_t)FILT_BYTES + (size_t)WAVES * NT_IN * tile_bytes;
+    auto kern = dwconv_mfma_kernel<K, KS, MODE, NSEG>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((long)C * chunks)), dim3(64 * WAVES), lds, st, in0, in1, wb, ws, o0,
+                       o1, N, C, H, W, G, band, bands, segs, items_per_channel, tile_bytes);
+    return launch_status();
+}
+
+// staged columns for a choice of NSEG (cost model: LDS staging traffic)
+template <int K>
+inline long staged_cols(int W, int nseg) {
+    const long segs = (W + 16 * nseg - 1) / (16 * nseg);
+    return segs * (16 * (nseg - 1) + 32 * Geo<K>::NS);
+}
+
+template <int K, int KS, int MODE>
+int launch_k(const uint16_t* in0, const uint16_t* in1, const float* wb, const float* ws, uint16_t* o0,
+             uint16_t* o1, int N, int C, int H, int W, hipStream_t st) {
+    const long c5 = staged_cols<K>(W, 5), c3 = staged_cols<K>(W, 3), c2 = staged_cols<K>(W, 2);
+    if (c5 <= c3 && c5 <= c2) return launch<K, KS, MODE, 5>(in0, in1, wb, ws, o0, o1, N, C, H, W, st);
+    if (c3 <= c2) return launch<K, KS, MODE, 3>(in0, in1, wb, ws, o0, o1, N, C, H, W, st);
+    return launch<K, KS, MODE, 2>(in0, in1, wb, ws, o0, o1, N, C, H, W, st);
+}
+
+template <int MODE>
+int dispatch(const uint16_t* in0, const uint16_t* in1, const float* wb, const float* ws, uint16_t* o0,
+             uint16_t* o1, int N, int C, int H, int W, int K, int KS, hipStream_t st) {
+#define PPEA_CASE(K_)                                                                             \
+    case K_:                                                                                      \
+        return KS == 5 ? launch_k<K_, 5, MODE>(in0, in1, wb, ws, o0, o1, N, C, H, W, st)          \
+                       : launch_k<K_, 0, MODE>(in0, in1, wb, ws, o0, o1, N, C, H, W, st);
+    switch (K) {
+        PPEA_CASE(31) PPEA_CASE(29) PPEA_CASE(27) PPEA_CASE(13)
+        default: return PPEA_ERR_UNSUPPORTED;
+    }
+#undef PPEA_CASE
+}
+
+}  // namespace
+
+// Internal entry points used by dwconv_lk.hip's bf16 ABI functions (same shared object).
+int ppea_internal_dwconv_mfma_fwd(const uint16_t* x, const float* wb, const float* ws, uint16_t* yb,
+                                  uint16_t* ys, int N, int C, int H, int W, int K, int KS, void* stream) {
+    if (N <= 0 || (KS != 0 && KS != 5)) return PPEA_ERR_UNSUPPORTED;
+    return dispatch<0>(x, nullptr, wb, ws, yb, ys, N, C, H, W, K, KS, (hipStream_t)stream);
+}
+int ppea_internal_dwconv_mfma_bwd(const uint16_t* dyb, const uint16_t* dys, const float* wb, const float* ws,
+                                  uint16_t* dx, int N, int C, int H, int W, int K, int KS, void* stream) {
+    if (N <= 0 || (KS != 0 && KS != 5)) return PPEA_ERR_UNSUPPORTED;
+    return dispatch<1>(dyb, dys, wb, ws, dx, nullptr, N, C, H, W, K, KS, (hipStream_t)stream);
+}
