@@ -22,6 +22,7 @@
 // dgrad: second input, same accumulator) costs 5 more MFMAs per tile.
 // Replaces nn.Conv2d(groups=C) at networks/replknet_adapter.py:225-239 under bf16 autocast.
 #include "common.h"
+#include <utility>
 
 namespace {
 
@@ -128,16 +129,78 @@ __device__ __forceinline__ void stage_planes(uint8_t* tile, const uint16_t* __re
 // acc += sum over filter rows of A(rows, chunk) * B(ky, chunk) for one 16x16 tile.
 // `abase` = LDS byte address of (first input row of this lane's output row, first chunk column of
 // the tile) + 16 * (lane >> 4); ROW0 = extra row offset (small kernel inside the big halo).
-template <int KK, int NS, int ROW0, int STRIDE_B>
-__device__ __forceinline__ void tile_mac(f32x4& acc, const uint8_t* abase, const bf16x8 (&bf)[KK][NS]) {
+// ---- hand-counted LDS pipeline ---------------------------------------------------------------------
+// hipcc sinks every ds_read next to its MFMA (one read in flight, ~100 exposed cycles per MFMA with one
+// wave per SIMD).  The A-fragment reads are therefore inline asm (invisible to the scheduler, issued in
+// program order) and their completion is counted by hand: LDS returns in order, so after issuing the
+// next group's n reads `s_waitcnt lgkmcnt(n)` means "the current group has landed".  The wait statement
+// names the current group's registers as in/out operands, which ties every consuming MFMA to it
+// (cdna_hip_programming.md 5.7, form (ii)).
+typedef __attribute__((address_space(3))) const uint8_t* lds_cptr_t;
+__device__ __forceinline__ uint32_t lds_addr(const uint8_t* p) { return (uint32_t)(uintptr_t)(lds_cptr_t)p; }
+
+template <int OFF>
+__device__ __forceinline__ void ds_read128_async(bf16x8& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+
+template <int N, int CNT>
+__device__ __forceinline__ void wait_lds(bf16x8 (&a)[N]) {
+    static_assert(N == 8 || N == 5, "group sizes used by tile_mac");
+    if constexpr (N == 8)
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+                     : "i"(CNT));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%5)"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4])
+                     : "i"(CNT));
+}
+
+template <int KK, int NS, int ROW0, int STRIDE_B, int GRP, int G, int I>
+__device__ __forceinline__ void issue_one(bf16x8 (&a)[GRP * NS], uint32_t abase) {
+    constexpr int r = I / NS, sidx = I % NS, ky = G * GRP + r;
+    if constexpr (ky < KK) ds_read128_async<(ky + ROW0) * STRIDE_B + sidx * 64>(a[I], abase);
+}
+
+template <int KK, int NS, int ROW0, int STRIDE_B, int GRP, int G, int... Is>
+__device__ __forceinline__ void issue_all(bf16x8 (&a)[GRP * NS], uint32_t abase, std::integer_sequence<int, Is...>) {
+    (issue_one<KK, NS, ROW0, STRIDE_B, GRP, G, Is>(a, abase), ...);
+}
+
+constexpr int group_reads(int KK, int NS, int GRP, int g) {
+    const int rows = (KK - g * GRP) < GRP ? (KK - g * GRP) : GRP;
+    return rows > 0 ? rows * NS : 0;
+}
+
+template <int KK, int NS, int ROW0, int STRIDE_B, int GRP, int G>
+__device__ __forceinline__ void mac_groups(f32x4& acc, bf16x8 (&cur)[GRP * NS], bf16x8 (&nxt)[GRP * NS],
+                                           uint32_t abase, const bf16x8 (&bf)[KK][NS]) {
+    constexpr int NG = (KK + GRP - 1) / GRP;
+    if constexpr (G < NG) {
+        if constexpr (G + 1 < NG)
+            issue_all<KK, NS, ROW0, STRIDE_B, GRP, G + 1>(nxt, abase, std::make_integer_sequence<int, GRP * NS>{});
+        wait_lds<GRP * NS, group_reads(KK, NS, GRP, G + 1)>(cur);
 #pragma unroll
-    for (int ky = 0; ky < KK; ++ky) {
+        for (int r = 0; r < GRP; ++r)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const uint4 av = *reinterpret_cast<const uint4*>(abase + (ky + ROW0) * STRIDE_B + s * 64);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), bf[ky][s], acc, 0, 0, 0);
-        }
+            for (int s = 0; s < NS; ++s) {
+                const int ky = G * GRP + r;
+                if (ky < KK) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[r * NS + s], bf[ky][s], acc, 0, 0, 0);
+            }
+        mac_groups<KK, NS, ROW0, STRIDE_B, GRP, G + 1>(acc, nxt, cur, abase, bf);
     }
+}
+
+// acc += sum over filter rows of A(rows, chunk) * B(ky, chunk) for one 16x16 tile.
+// `abase` = LDS byte address of (first input row of this lane's output row, first chunk column of
+// the tile) + 16 * (lane >> 4); ROW0 = extra row offset (small kernel inside the big halo).
+template <int KK, int NS, int ROW0, int STRIDE_B>
+__device__ __forceinline__ void tile_mac(f32x4& acc, uint32_t abase, const bf16x8 (&bf)[KK][NS]) {
+    constexpr int GRP = (NS == 2) ? 4 : 5;
+    bf16x8 a0[GRP * NS], a1[GRP * NS];
+    issue_all<KK, NS, ROW0, STRIDE_B, GRP, 0>(a0, abase, std::make_integer_sequence<int, GRP * NS>{});
+    mac_groups<KK, NS, ROW0, STRIDE_B, GRP, 0>(acc, a0, a1, abase, bf);
 }
 
 __device__ __forceinline__ void store_tile(uint16_t* __restrict__ dst, const f32x4& acc, const Item& it, int C,
@@ -164,6 +227,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
     constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
     constexpr int FILT_BYTES = ((2 * K * WPAD + 2 * KS * WPAD) * 2 + 15) & ~15;
+    constexpr int AGPR_FROM = 6;             // big-filter fragments [AGPR_FROM, K*NS) live in AGPRs
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // layout: [filter big: 2*K*WPAD u16][filter small: 2*KS*WPAD u16][WAVES x NT_IN input tiles]
     uint16_t* wimg_b = reinterpret_cast<uint16_t*>(smem);
@@ -214,6 +278,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
 #pragma unroll
         for (int s = 0; s < GE::NS; ++s)
             bf_big[ky][s] = load_bfrag<GE::P, GE::JOFF>(wimg_b + ky * WPAD, wimg_b + (K + ky) * WPAD, s, lane);
+    // Park most Toeplitz fragments in the accumulator half of the unified register file (MFMA reads its
+    // B operand from AGPRs directly); this keeps the arch VGPRs free for A-fragment prefetch.
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int s = 0; s < GE::NS; ++s)
+            if (ky * GE::NS + s >= AGPR_FROM) asm volatile("" : "+a"(bf_big[ky][s]));
     bf16x8 bf_small[(KS > 0 ? KS : 1)][1];
     if constexpr (KS > 0) {
 #pragma unroll
@@ -233,8 +304,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
         const int m = min(mt * 16 + (lane & 15), mrows - 1);
         const int g = m / it.rows, y = m - g * it.rows;
         const long aoff = (long)(g * rows_l + y) * STRIDE_B + 16 * (lane >> 4);
-        const uint8_t* arow0 = tile0 + aoff;
-        const uint8_t* arow1 = tile1 + aoff;
+        const uint32_t arow0 = lds_addr(tile0 + aoff);
+        const uint32_t arow1 = lds_addr(tile1 + aoff);
         for (int nt = 0; nt < ntiles_x; ++nt) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             tile_mac<K, GE::NS, 0, STRIDE_B>(acc, arow0 + nt * 32, bf_big);

@@ -81,19 +81,36 @@ def test_dwconv_golden_reference(device, golden):
         assert rel_err(ys.cpu(), g[f"lk{k}:y_small_conv"]) < FWD_TOL
 
 
-def test_dwconv_bf16_io(device):
-    """bf16 I/O, fp32 accumulate: exact up to one output rounding vs the oracle on bf16-rounded x."""
+@pytest.mark.parametrize("K,N,C,H,W", [(31, 3, 4, 48, 160), (29, 4, 4, 24, 80), (27, 5, 4, 12, 40), (13, 7, 4, 6, 20),
+                                       (31, 2, 3, 48, 128), (29, 2, 3, 24, 64), (27, 3, 3, 12, 32), (13, 3, 3, 6, 16),
+                                       (31, 2, 2, 70, 37), (27, 1, 2, 33, 90), (13, 2, 2, 17, 9), (31, 1, 1, 1, 1),
+                                       (31, 2, 2, 128, 256)])
+def test_dwconv_bf16_mfma(device, K, N, C, H, W):
+    """bf16 I/O on the matrix cores (banded-Toeplitz MFMA kernel): bf16 activations and bf16-rounded
+    filters (what autocast feeds a conv), fp32 accumulation, one bf16 rounding of the output."""
     ops = _ops()
-    N, C, H, W, K = 2, 8, 24, 40, 31
-    x = torch.randn(N, C, H, W, generator=_g(7)).bfloat16()
+    x = torch.randn(N, C, H, W, generator=_g(K + H)).bfloat16()
     wb = torch.randn(C, 1, K, K, generator=_g(8)) / K
     ws = torch.randn(C, 1, 5, 5, generator=_g(9)) / 5
-    yb, ys = ops.dwconv_lk(x.to(device), wb.to(device), ws.to(device))
+    wbq, wsq = wb.bfloat16().float(), ws.bfloat16().float()
+
+    def close(a, ref):
+        a = a.float().cpu()
+        return bool(((a - ref).abs() <= ref.abs() * 2 ** -7 + ref.abs().max() * 1e-3 + 1e-6).all())
+
+    xd = x.to(device).requires_grad_(True)
+    yb, ys = ops.dwconv_lk(xd, wb.to(device), ws.to(device))
     assert yb.dtype == torch.bfloat16
-    ref = R.dwconv(x.float(), wb)
-    assert (yb.float().cpu() - ref).abs().max() <= ref.abs().max() * 2 ** -8 + 1e-6
-    refs = R.dwconv(x.float(), ws)
-    assert (ys.float().cpu() - refs).abs().max() <= refs.abs().max() * 2 ** -8 + 1e-6
+    assert close(yb, R.dwconv(x.float(), wbq))
+    assert close(ys, R.dwconv(x.float(), wsq))
+    y1, none = ops.dwconv_lk(x.to(device), wb.to(device), None)          # big branch alone
+    assert none is None and close(y1, R.dwconv(x.float(), wbq))
+    gb = torch.randn(N, C, H, W, generator=_g(3)).bfloat16()
+    gs = torch.randn(N, C, H, W, generator=_g(4)).bfloat16()
+    torch.autograd.backward([yb, ys], [gb.to(device), gs.to(device)])
+    xr = x.float().clone().requires_grad_(True)
+    (R.dwconv(xr, wbq) * gb.float() + R.dwconv(xr, wsq) * gs.float()).sum().backward()
+    assert close(xd.grad, xr.grad)
 
 
 def test_dwconv_linearity_full_size(device):
