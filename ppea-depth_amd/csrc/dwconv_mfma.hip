@@ -93,42 +93,44 @@ struct Item {
     int x0;        // first output column of the segment
 };
 
-// Stage G planes' rows [y0 - P, y0 + rows + P) x cols [x0 - JOFF, x0 - JOFF + WL) into LDS (bf16, zeros outside).
+// Stage G planes' rows [y0 - P, y0 + rows + P) x cols [x0 - JOFF, x0 - JOFF + WL) into LDS (bf16, zeros
+// outside).  Lane -> (row within a block of 64/CG rows, 16-byte column group); no divisions in the loop.
 template <int K, int NSEG>
 __device__ __forceinline__ void stage_planes(uint8_t* tile, const uint16_t* __restrict__ src, const Item& it,
                                              int C, int c, int H, int W, int lane) {
     using GE = Geo<K>;
-    constexpr int WL = Seg<K, NSEG>::WL;
+    constexpr int CG = Seg<K, NSEG>::WL / 8;                   // 16-byte groups per staged row
+    constexpr int RPI = 64 / CG;                               // rows per wave iteration
     constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
+    const int r_in = lane / CG, cg = lane - r_in * CG;
+    if (r_in >= RPI) return;
     const int rows_l = it.rows + K - 1;                        // LDS rows per image
-    const int total = it.G * rows_l * (WL / 8);
-    const bool vec_ok = ((W & 7) == 0);
-    for (int i = lane; i < total; i += WAVE) {
-        const int cg = i % (WL / 8);
-        const int rr = i / (WL / 8);
-        const int g = rr / rows_l, r = rr - g * rows_l;
-        const int gy = it.y0 - GE::P + r;
-        const int gx = it.x0 - GE::JOFF + cg * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (gy >= 0 && gy < H) {
-            const uint16_t* rowp = src + (((long)(it.n0 + g) * C + c) * H + gy) * W;
-            if (vec_ok && gx >= 0 && gx + 8 <= W) {
-                v = *reinterpret_cast<const uint4*>(rowp + gx);
-            } else {
-                uint16_t e[8];
+    const int gx = it.x0 - GE::JOFF + cg * 8;
+    const bool vec_ok = ((W & 7) == 0) && gx >= 0 && gx + 8 <= W;
+    const bool any_col = gx + 8 > 0 && gx < W;
+    for (int g = 0; g < it.G; ++g) {
+        const uint16_t* plane = src + ((long)(it.n0 + g) * C + c) * (long)H * W;
+        uint8_t* dst = tile + ((long)g * rows_l + r_in) * STRIDE_B + cg * 16;
+        int gy = it.y0 - GE::P + r_in;
+        for (int r = r_in; r < rows_l; r += RPI, gy += RPI, dst += RPI * STRIDE_B) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (gy >= 0 && gy < H && any_col) {
+                const uint16_t* rowp = plane + (long)gy * W;
+                if (vec_ok) {
+                    v = *reinterpret_cast<const uint4*>(rowp + gx);
+                } else {
+                    uint16_t e[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) e[k] = (gx + k >= 0 && gx + k < W) ? rowp[gx + k] : (uint16_t)0;
-                v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
-                v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+                    for (int k = 0; k < 8; ++k) e[k] = (gx + k >= 0 && gx + k < W) ? rowp[gx + k] : (uint16_t)0;
+                    v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
+                    v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+                }
             }
+            *reinterpret_cast<uint4*>(dst) = v;
         }
-        *reinterpret_cast<uint4*>(tile + (long)rr * STRIDE_B + cg * 16) = v;
     }
 }
 
-// acc += sum over filter rows of A(rows, chunk) * B(ky, chunk) for one 16x16 tile.
-// `abase` = LDS byte address of (first input row of this lane's output row, first chunk column of
-// the tile) + 16 * (lane >> 4); ROW0 = extra row offset (small kernel inside the big halo).
 // ---- hand-counted LDS pipeline ---------------------------------------------------------------------
 // hipcc sinks every ds_read next to its MFMA (one read in flight, ~100 exposed cycles per MFMA with one
 // wave per SIMD).  The A-fragment reads are therefore inline asm (invisible to the scheduler, issued in
@@ -203,16 +205,31 @@ __device__ __forceinline__ void tile_mac(f32x4& acc, uint32_t abase, const bf16x
     mac_groups<KK, NS, ROW0, STRIDE_B, GRP, 0>(acc, a0, a1, abase, bf);
 }
 
-__device__ __forceinline__ void store_tile(uint16_t* __restrict__ dst, const f32x4& acc, const Item& it, int C,
-                                           int c, int H, int W, int mt, int xt, int lane) {
-    const int col = xt + (lane & 15);
+// Per M-tile: element offsets of this lane's four output rows (-1 = padding row).
+struct RowOffs { int off[4]; };
+
+__device__ __forceinline__ RowOffs row_offsets(const Item& it, int C, int c, int H, int W, int mt, int lane) {
+    RowOffs ro;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = mt * 16 + 4 * (lane >> 4) + i;           // stacked output row
         const int g = m / it.rows, y = it.y0 + (m - g * it.rows);
-        if (g < it.G && y < H && col < W)
-            dst[(((long)(it.n0 + g) * C + c) * H + y) * W + col] = f32_to_bf16(acc[i]);
+        ro.off[i] = (g < it.G && y < H) ? (((it.n0 + g) * C + c) * H + y) * W : -1;
     }
+    return ro;
+}
+
+__device__ __forceinline__ uint16_t to_bf16_hw(float f) {      // v_cvt_pk_bf16_f32 (RNE, NaN kept)
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
+
+__device__ __forceinline__ void store_tile(uint16_t* __restrict__ dst, const f32x4& acc, const RowOffs& ro, int W,
+                                           int xt, int lane) {
+    const int col = xt + (lane & 15);
+    if (col >= W) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ro.off[i] >= 0) dst[ro.off[i] + col] = to_bf16_hw(acc[i]);
 }
 
 // MODE 0: fwd  (in0 = x; out0 = y_big, out1 = y_small if KS)
@@ -221,7 +238,7 @@ template <int K, int KS, int MODE, int NSEG>
 __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     const uint16_t* __restrict__ in0, const uint16_t* __restrict__ in1, const float* __restrict__ w_big,
     const float* __restrict__ w_small, uint16_t* __restrict__ out0, uint16_t* __restrict__ out1, int N, int C,
-    int H, int W, int G, int band, int bands, int segs, int items_per_channel, int tile_bytes) {
+    int H, int W, int G, int band, int bands, int segs, int items_per_channel, int ipw, int tile_bytes) {
     using GE = Geo<K>;
     using GS = Geo<(KS > 0 ? KS : 5)>;
     constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
@@ -235,40 +252,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int chunks_per_channel = (items_per_channel + WAVES - 1) / WAVES;
+    const int per_wg = WAVES * ipw;
+    const int chunks_per_channel = (items_per_channel + per_wg - 1) / per_wg;
     const int c = blockIdx.x / chunks_per_channel;
-    const int item_id = (blockIdx.x - c * chunks_per_channel) * WAVES + wave;
-    const bool active = item_id < items_per_channel;
+    const int first_item = (blockIdx.x - c * chunks_per_channel) * per_wg + wave * ipw;
 
     stage_filter<K>(wimg_b, w_big + (long)c * K * K, MODE == 1, threadIdx.x, 64 * WAVES);
     if constexpr (KS > 0) stage_filter<KS>(wimg_s, w_small + (long)c * KS * KS, MODE == 1, threadIdx.x, 64 * WAVES);
-
-    Item it;                                 // item = (plane group or row band, column segment)
-    {
-        const int id = active ? item_id : 0;
-        const int seg = id % segs;
-        const int gb = id / segs;
-        it.x0 = seg * 16 * NSEG;
-        if (G > 1) {                         // G small planes stacked along M, whole height
-            it.n0 = gb * G;
-            it.G = min(G, N - it.n0);
-            it.y0 = 0;
-            it.rows = H;
-        } else {                             // one plane, bands of `band` rows
-            it.n0 = gb / bands;
-            it.G = 1;
-            it.y0 = (gb - it.n0 * bands) * band;
-            it.rows = min(band, H - it.y0);
-        }
-    }
-    const int rows_l = it.rows + K - 1;      // LDS rows per stacked image (with halo)
-    uint8_t* tile0 = smem + FILT_BYTES + (long)wave * NT_IN * tile_bytes;
-    uint8_t* tile1 = tile0 + tile_bytes;
-
-    if (active) {
-        stage_planes<K, NSEG>(tile0, in0, it, C, c, H, W, lane);
-        if constexpr (NT_IN == 2) stage_planes<K, NSEG>(tile1, in1, it, C, c, H, W, lane);
-    }
     __syncthreads();
 
     // Toeplitz fragments of the whole filter: registers for the rest of the kernel
@@ -291,36 +281,67 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
         for (int ky = 0; ky < KS; ++ky)
             bf_small[ky][0] = load_bfrag<GS::P, GS::JOFF>(wimg_s + ky * WPAD, wimg_s + (KS + ky) * WPAD, 0, lane);
     }
-    if (!active) return;
 
-    const int ntiles_x = min(NSEG, (W - it.x0 + 15) / 16);
-    const int mrows = it.G * it.rows;
-    const int ntiles_m = (mrows + 15) / 16;
+    uint8_t* tile0 = smem + FILT_BYTES + (long)wave * NT_IN * tile_bytes;
+    uint8_t* tile1 = tile0 + tile_bytes;
     constexpr int SM_ROW0 = GE::P - GS::P;                  // small-kernel rows inside the big halo
     constexpr int SM_COLB = (GE::JOFF - GS::JOFF) * 2;      // byte offset of its first chunk
 
-    for (int mt = 0; mt < ntiles_m; ++mt) {
-        // this lane's output row -> first LDS row of its window (clamped for padding rows)
-        const int m = min(mt * 16 + (lane & 15), mrows - 1);
-        const int g = m / it.rows, y = m - g * it.rows;
-        const long aoff = (long)(g * rows_l + y) * STRIDE_B + 16 * (lane >> 4);
-        const uint32_t arow0 = lds_addr(tile0 + aoff);
-        const uint32_t arow1 = lds_addr(tile1 + aoff);
-        for (int nt = 0; nt < ntiles_x; ++nt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            tile_mac<K, GE::NS, 0, STRIDE_B>(acc, arow0 + nt * 32, bf_big);
-            if constexpr (MODE == 0) {
-                store_tile(out0, acc, it, C, c, H, W, mt, it.x0 + nt * 16, lane);
-                if constexpr (KS > 0) {
-                    f32x4 acs = {0.f, 0.f, 0.f, 0.f};
-                    tile_mac<KS, 1, SM_ROW0, STRIDE_B>(acs, arow0 + nt * 32 + SM_COLB, bf_small);
-                    store_tile(out1, acs, it, C, c, H, W, mt, it.x0 + nt * 16, lane);
-                }
-            } else {
-                if constexpr (KS > 0) tile_mac<KS, 1, SM_ROW0, STRIDE_B>(acc, arow1 + nt * 32 + SM_COLB, bf_small);
-                store_tile(out0, acc, it, C, c, H, W, mt, it.x0 + nt * 16, lane);
+    for (int k = 0; k < ipw; ++k) {
+        const int item_id = first_item + k;                 // wave-uniform
+        if (item_id >= items_per_channel) break;
+        Item it;                                            // item = (plane group or row band, column segment)
+        {
+            const int seg = item_id % segs;
+            const int gb = item_id / segs;
+            it.x0 = seg * 16 * NSEG;
+            if (G > 1) {                                    // G small planes stacked along M, whole height
+                it.n0 = gb * G;
+                it.G = min(G, N - it.n0);
+                it.y0 = 0;
+                it.rows = H;
+            } else {                                        // one plane, bands of `band` rows
+                it.n0 = gb / bands;
+                it.G = 1;
+                it.y0 = (gb - it.n0 * bands) * band;
+                it.rows = min(band, H - it.y0);
             }
         }
+        // The tile is wave-private: LDS operations of one wave execute in order, so the staging writes
+        // below are ordered after the previous item's (already waited-for) reads and before this item's.
+        stage_planes<K, NSEG>(tile0, in0, it, C, c, H, W, lane);
+        if constexpr (NT_IN == 2) stage_planes<K, NSEG>(tile1, in1, it, C, c, H, W, lane);
+        asm volatile("" ::: "memory");      // compiler fence: staging stores stay above the asm LDS reads
+
+        const int rows_l = it.rows + K - 1;                 // LDS rows per stacked image (with halo)
+        const int ntiles_x = min(NSEG, (W - it.x0 + 15) / 16);
+        const int mrows = it.G * it.rows;
+        const int ntiles_m = (mrows + 15) / 16;
+        for (int mt = 0; mt < ntiles_m; ++mt) {
+            // this lane's A row -> first LDS row of its window (clamped for padding rows)
+            const int m = min(mt * 16 + (lane & 15), mrows - 1);
+            const int g = m / it.rows, y = m - g * it.rows;
+            const long aoff = (long)(g * rows_l + y) * STRIDE_B + 16 * (lane >> 4);
+            const uint32_t arow0 = lds_addr(tile0 + aoff);
+            const uint32_t arow1 = lds_addr(tile1 + aoff);
+            const RowOffs ro = row_offsets(it, C, c, H, W, mt, lane);
+            for (int nt = 0; nt < ntiles_x; ++nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                tile_mac<K, GE::NS, 0, STRIDE_B>(acc, arow0 + nt * 32, bf_big);
+                if constexpr (MODE == 0) {
+                    store_tile(out0, acc, ro, W, it.x0 + nt * 16, lane);
+                    if constexpr (KS > 0) {
+                        f32x4 acs = {0.f, 0.f, 0.f, 0.f};
+                        tile_mac<KS, 1, SM_ROW0, STRIDE_B>(acs, arow0 + nt * 32 + SM_COLB, bf_small);
+                        store_tile(out1, acs, ro, W, it.x0 + nt * 16, lane);
+                    }
+                } else {
+                    if constexpr (KS > 0) tile_mac<KS, 1, SM_ROW0, STRIDE_B>(acc, arow1 + nt * 32 + SM_COLB, bf_small);
+                    store_tile(out0, acc, ro, W, it.x0 + nt * 16, lane);
+                }
+            }
+        }
+        asm volatile("" ::: "memory");      // next item's staging stores stay below this item's LDS reads
     }
 }
 
@@ -347,7 +368,15 @@ int launch(const uint16_t* in0, const uint16_t* in1, const float* wb, const floa
     const int segs = (W + 16 * NSEG - 1) / (16 * NSEG);
     const int groups = (G > 1) ? (N + G - 1) / G : N * bands;
     const int items_per_channel = groups * segs;
-    const int chunks = (items_per_channel + WAVES - 1) / WAVES;
+    if ((long)N * C * H * W >= (1L << 31)) return PPEA_ERR_UNSUPPORTED;      // 32-bit element offsets
+    // items per wave: amortise filter staging / fragment build while keeping >= ~256 workgroups
+    int ipw = 1;
+    for (int cand = 2; cand <= 8; ++cand) {
+        const long wgs = (long)C * ((items_per_channel + WAVES * cand - 1) / (WAVES * cand));
+        const bool even = (items_per_channel % (WAVES * cand)) == 0;
+        if (wgs >= 256 && even) ipw = cand;
+    }
+    const int chunks = (items_per_channel + WAVES * ipw - 1) / (WAVES * ipw);
     const size_t lds = (size_t)FILT_BYTES + (size_t)WAVES * NT_IN * tile_bytes;
     auto kern = dwconv_mfma_kernel<K, KS, MODE, NSEG>;
     static bool attr_done = false;
@@ -356,7 +385,7 @@ int launch(const uint16_t* in0, const uint16_t* in1, const float* wb, const floa
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((long)C * chunks)), dim3(64 * WAVES), lds, st, in0, in1, wb, ws, o0,
-                       o1, N, C, H, W, G, band, bands, segs, items_per_channel, tile_bytes);
+                       o1, N, C, H, W, G, band, bands, segs, items_per_channel, ipw, tile_bytes);
     return launch_status();
 }
 
