@@ -238,28 +238,37 @@ template <int K, int KS, int MODE, int NSEG>
 __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     const uint16_t* __restrict__ in0, const uint16_t* __restrict__ in1, const float* __restrict__ w_big,
     const float* __restrict__ w_small, uint16_t* __restrict__ out0, uint16_t* __restrict__ out1, int N, int C,
-    int H, int W, int G, int band, int bands, int segs, int items_per_channel, int ipw, int tile_bytes) {
+    int H, int W, int G, int band, int bands, int segs, int items_per_channel, int ipw, int wpc,
+    long total_waves, int tile_bytes, int region_bytes) {
     using GE = Geo<K>;
     using GS = Geo<(KS > 0 ? KS : 5)>;
     constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
     constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
-    constexpr int FILT_BYTES = ((2 * K * WPAD + 2 * KS * WPAD) * 2 + 15) & ~15;
     constexpr int AGPR_FROM = 6;             // big-filter fragments [AGPR_FROM, K*NS) live in AGPRs
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // layout: [filter big: 2*K*WPAD u16][filter small: 2*KS*WPAD u16][WAVES x NT_IN input tiles]
-    uint16_t* wimg_b = reinterpret_cast<uint16_t*>(smem);
-    uint16_t* wimg_s = wimg_b + 2 * K * WPAD;
-
+    // One LDS region per wave: first the padded filter image of the wave's channel (needed only while
+    // the Toeplitz fragments are built), then overlaid by the wave's input tile(s).
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int per_wg = WAVES * ipw;
-    const int chunks_per_channel = (items_per_channel + per_wg - 1) / per_wg;
-    const int c = blockIdx.x / chunks_per_channel;
-    const int first_item = (blockIdx.x - c * chunks_per_channel) * per_wg + wave * ipw;
-
-    stage_filter<K>(wimg_b, w_big + (long)c * K * K, MODE == 1, threadIdx.x, 64 * WAVES);
-    if constexpr (KS > 0) stage_filter<KS>(wimg_s, w_small + (long)c * KS * KS, MODE == 1, threadIdx.x, 64 * WAVES);
+    const long wid0 = (long)blockIdx.x * WAVES;
+    // filter images of the workgroup's (up to) four channels, staged by all 256 threads
+#pragma unroll 1
+    for (int w = 0; w < WAVES; ++w) {
+        const long wid = wid0 + w;
+        if (wid >= total_waves) break;
+        const int cw = (int)(wid / wpc);
+        uint16_t* img = reinterpret_cast<uint16_t*>(smem + (long)w * region_bytes);
+        stage_filter<K>(img, w_big + (long)cw * K * K, MODE == 1, threadIdx.x, 64 * WAVES);
+        if constexpr (KS > 0)
+            stage_filter<KS>(img + 2 * K * WPAD, w_small + (long)cw * KS * KS, MODE == 1, threadIdx.x, 64 * WAVES);
+    }
     __syncthreads();
+    const long wid = wid0 + wave;
+    if (wid >= total_waves) return;
+    const int c = (int)(wid / wpc);
+    const int first_item = (int)(wid - (long)c * wpc) * ipw;
+    uint16_t* wimg_b = reinterpret_cast<uint16_t*>(smem + (long)wave * region_bytes);
+    uint16_t* wimg_s = wimg_b + 2 * K * WPAD;
 
     // Toeplitz fragments of the whole filter: registers for the rest of the kernel
     bf16x8 bf_big[K][GE::NS];
@@ -281,8 +290,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
         for (int ky = 0; ky < KS; ++ky)
             bf_small[ky][0] = load_bfrag<GS::P, GS::JOFF>(wimg_s + ky * WPAD, wimg_s + (KS + ky) * WPAD, 0, lane);
     }
+    // the fragment reads above must have completed before the tile staging overwrites the image
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-    uint8_t* tile0 = smem + FILT_BYTES + (long)wave * NT_IN * tile_bytes;
+    uint8_t* tile0 = smem + (long)wave * region_bytes;
     uint8_t* tile1 = tile0 + tile_bytes;
     constexpr int SM_ROW0 = GE::P - GS::P;                  // small-kernel rows inside the big halo
     constexpr int SM_COLB = (GE::JOFF - GS::JOFF) * 2;      // byte offset of its first chunk
@@ -351,15 +362,17 @@ int launch(const uint16_t* in0, const uint16_t* in1, const float* wb, const floa
     constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
     constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
     constexpr int FILT_BYTES = ((2 * K * WPAD + 2 * KS * WPAD) * 2 + 15) & ~15;
-    // largest band / stacking that fits the 160 KB of LDS with four waves per workgroup
-    int band = 0, G = 1, tile_bytes = 0;
+    if ((long)N * C * H * W >= (1L << 31)) return PPEA_ERR_UNSUPPORTED;      // 32-bit element offsets
+    // largest band / stacking whose per-wave region fits four times into the 160 KB of LDS
+    int band = 0, G = 1, tile_bytes = 0, region = 0;
     for (int cand : {48, 32, 16}) {
         int g = (H < cand) ? (cand / H < N ? cand / H : N) : 1;
         if (g < 1) g = 1;
         for (; g >= 1; --g) {
             const int rows = (g > 1) ? g * (H + K - 1) : ((H < cand ? H : cand) + K - 1);
             const int tb = (rows * STRIDE_B + 15) & ~15;
-            if (FILT_BYTES + WAVES * NT_IN * tb <= LDS_LIMIT) { band = cand; G = g; tile_bytes = tb; break; }
+            const int reg = (NT_IN * tb > FILT_BYTES) ? NT_IN * tb : FILT_BYTES;
+            if (WAVES * reg <= LDS_LIMIT) { band = cand; G = g; tile_bytes = tb; region = reg; break; }
         }
         if (band) break;
     }
@@ -368,24 +381,24 @@ int launch(const uint16_t* in0, const uint16_t* in1, const float* wb, const floa
     const int segs = (W + 16 * NSEG - 1) / (16 * NSEG);
     const int groups = (G > 1) ? (N + G - 1) / G : N * bands;
     const int items_per_channel = groups * segs;
-    if ((long)N * C * H * W >= (1L << 31)) return PPEA_ERR_UNSUPPORTED;      // 32-bit element offsets
-    // items per wave: amortise filter staging / fragment build while keeping >= ~256 workgroups
-    int ipw = 1;
-    for (int cand = 2; cand <= 8; ++cand) {
-        const long wgs = (long)C * ((items_per_channel + WAVES * cand - 1) / (WAVES * cand));
-        const bool even = (items_per_channel % (WAVES * cand)) == 0;
-        if (wgs >= 256 && even) ipw = cand;
-    }
-    const int chunks = (items_per_channel + WAVES * ipw - 1) / (WAVES * ipw);
-    const size_t lds = (size_t)FILT_BYTES + (size_t)WAVES * NT_IN * tile_bytes;
+    // waves per channel: ~one wave per SIMD over the whole chip (1024), each wave keeps its channel's
+    // Toeplitz fragments in registers and walks `ipw` items
+    int wpc = 1024 / C;
+    if (wpc < 1) wpc = 1;
+    if (wpc > items_per_channel) wpc = items_per_channel;
+    const int ipw = (items_per_channel + wpc - 1) / wpc;
+    wpc = (items_per_channel + ipw - 1) / ipw;
+    const long total_waves = (long)C * wpc;
+    const size_t lds = (size_t)WAVES * region;
     auto kern = dwconv_mfma_kernel<K, KS, MODE, NSEG>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((long)C * chunks)), dim3(64 * WAVES), lds, st, in0, in1, wb, ws, o0,
-                       o1, N, C, H, W, G, band, bands, segs, items_per_channel, ipw, tile_bytes);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((total_waves + WAVES - 1) / WAVES)), dim3(64 * WAVES), lds, st, in0,
+                       in1, wb, ws, o0, o1, N, C, H, W, G, band, bands, segs, items_per_channel, ipw, wpc,
+                       total_waves, tile_bytes, region);
     return launch_status();
 }
 
