@@ -51,6 +51,23 @@ int ppea_dwconv_lk_bwd_data_bf16(const uint16_t* dy_big, const uint16_t* dy_smal
                                  const float* w_big, const float* w_small, uint16_t* dx,
                                  int N, int C, int H, int W, int K, int KS, void* stream);
 
+/* bf16 on the matrix cores (banded-Toeplitz MFMA kernel, csrc/dwconv_mfma.hip).  The filters are packed
+ * ONCE per weight version (they are frozen in PPEA-Depth Stage 1/2, repdepth.py:47-50) into a bf16 image
+ * from which every wave builds its register-resident Toeplitz fragments:
+ *   ppea_dwconv_lk_packed_bytes(C, K)            size of the packed buffer for w [C,1,K,K]
+ *   ppea_dwconv_lk_pack_bf16(w, packed, C, K, flip)   flip = 0 for fwd, 1 for dgrad (both axes reversed)
+ *   ppea_dwconv_lk_fwd_bf16p / _bwd_data_bf16p   as the _bf16 entry points above, with packed filters
+ *                                                (packed_small may be NULL; KS in {0, 5}; K in {31,29,27,13}).
+ * Returns PPEA_ERR_UNSUPPORTED for shapes it does not serve; callers then use the _bf16 entry points. */
+long ppea_dwconv_lk_packed_bytes(int C, int K);
+int ppea_dwconv_lk_pack_bf16(const float* w, void* packed, int C, int K, int flip, void* stream);
+int ppea_dwconv_lk_fwd_bf16p(const uint16_t* x, const void* packed_big, const void* packed_small,
+                             uint16_t* y_big, uint16_t* y_small,
+                             int N, int C, int H, int W, int K, int KS, void* stream);
+int ppea_dwconv_lk_bwd_data_bf16p(const uint16_t* dy_big, const uint16_t* dy_small,
+                                  const void* packed_big_flip, const void* packed_small_flip,
+                                  uint16_t* dx, int N, int C, int H, int W, int K, int KS, void* stream);
+
 /* wgrad (only needed with --fullft_reb, repdepth.py:47, and by the plug-in's weight.grad):
  * dw[c,0,u,v] = sum_{n,i,j} dy[n,c,i,j] * x[n,c,i+u-K/2,j+v-K/2].  dw is overwritten. */
 int ppea_dwconv_lk_bwd_filter_f32(const float* x, const float* dy, float* dw,

@@ -348,21 +348,6 @@ int bwd_impl(const T* dyb, const T* dys, const float* wb, const float* ws, T* dx
 
 }  // namespace
 
-// bf16 path on the matrix cores (dwconv_mfma.hip); PPEA_ERR_UNSUPPORTED -> vector-FMA kernels above.
-int ppea_internal_dwconv_mfma_fwd(const uint16_t* x, const float* wb, const float* ws, uint16_t* yb,
-                                  uint16_t* ys, int N, int C, int H, int W, int K, int KS, void* stream);
-int ppea_internal_dwconv_mfma_bwd(const uint16_t* dyb, const uint16_t* dys, const float* wb, const float* ws,
-                                  uint16_t* dx, int N, int C, int H, int W, int K, int KS, void* stream);
-
-static bool use_mfma() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("PPEA_DWCONV_BF16");      // "valu" forces the vector-FMA kernels (A/B tests)
-        v = (e != nullptr && e[0] == 'v') ? 0 : 1;
-    }
-    return v == 1;
-}
-
 extern "C" {
 
 int ppea_abi_version(void) { return PPEA_ABI_VERSION; }
@@ -373,15 +358,6 @@ int ppea_dwconv_lk_fwd_f32(const float* x, const float* w_big, const float* w_sm
 }
 int ppea_dwconv_lk_fwd_bf16(const uint16_t* x, const float* w_big, const float* w_small, uint16_t* y_big,
                             uint16_t* y_small, int N, int C, int H, int W, int K, int KS, void* stream) {
-    if (use_mfma() && !bad_shape(N, C, H, W, K, KS) && N > 0) {
-        const bool small = (w_small != nullptr && y_small != nullptr && KS == 5);
-        if (small || KS == 0 || w_small == nullptr || y_small == nullptr) {
-            const int r = ppea_internal_dwconv_mfma_fwd(x, w_big, small ? w_small : nullptr, y_big,
-                                                        small ? y_small : nullptr, N, C, H, W, K, small ? 5 : 0,
-                                                        stream);
-            if (r != PPEA_ERR_UNSUPPORTED) return r;
-        }
-    }
     return fwd_impl<uint16_t>(x, w_big, w_small, y_big, y_small, N, C, H, W, K, KS, stream);
 }
 int ppea_dwconv_lk_bwd_data_f32(const float* dy_big, const float* dy_small, const float* w_big,
@@ -392,15 +368,6 @@ int ppea_dwconv_lk_bwd_data_f32(const float* dy_big, const float* dy_small, cons
 int ppea_dwconv_lk_bwd_data_bf16(const uint16_t* dy_big, const uint16_t* dy_small, const float* w_big,
                                  const float* w_small, uint16_t* dx, int N, int C, int H, int W, int K,
                                  int KS, void* stream) {
-    if (use_mfma() && !bad_shape(N, C, H, W, K, KS) && N > 0) {
-        const bool small = (w_small != nullptr && dy_small != nullptr && KS == 5);
-        if (small || KS == 0 || w_small == nullptr || dy_small == nullptr) {
-            const int r = ppea_internal_dwconv_mfma_bwd(dy_big, small ? dy_small : nullptr, w_big,
-                                                        small ? w_small : nullptr, dx, N, C, H, W, K,
-                                                        small ? 5 : 0, stream);
-            if (r != PPEA_ERR_UNSUPPORTED) return r;
-        }
-    }
     return bwd_impl<uint16_t>(dy_big, dy_small, w_big, w_small, dx, N, C, H, W, K, KS, stream);
 }
 int ppea_dwconv_lk_bwd_filter_f32(const float* x, const float* dy, float* dw, int N, int C, int H, int W,

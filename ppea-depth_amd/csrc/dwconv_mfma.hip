@@ -55,34 +55,43 @@ struct Seg {
     static constexpr int STRIDE = lds_stride_bytes(WL);
 };
 
-// B fragment for (filter row `wrow` of the padded LDS image, chunk s): taps t0..t0+7 with
-// t0 = 32*s + 8*(lane>>4) - (lane&15) + (P - JOFF); two LDS copies (even / odd alignment) keep the
-// reads 4-byte aligned.
-template <int P, int JOFF>
-__device__ __forceinline__ bf16x8 load_bfrag(const uint16_t* wrow_even, const uint16_t* wrow_odd, int s,
-                                             int lane) {
-    const int t0 = 32 * s + 8 * (lane >> 4) - (lane & 15) + (P - JOFF);
-    const int i0 = t0 + 32;                                   // index into the padded row, in [0, WPAD-8]
-    const uint16_t* src = (i0 & 1) ? (wrow_odd + (i0 - 1)) : (wrow_even + i0);
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(src);
-    uint4 v;
-    v.x = p[0]; v.y = p[1]; v.z = p[2]; v.w = p[3];
-    return __builtin_bit_cast(bf16x8, v);
+// Packed filter image (built once per weight version by ppea_dwconv_lk_pack_bf16):
+//   img[c][copy 0..3][ky][WPAD] bf16,  img[..][copy][ky][i] = wpad[ky][i + copy],
+//   wpad[ky][i] = w[ky][i - 32] for 0 <= i - 32 < K, else 0   (dgrad: both filter axes reversed).
+// The B fragment of (ky, chunk s) for lane l is wpad[ky][i0 .. i0+7], i0 = 32 + 32*s + 8*(l>>4) - (l&15)
+// + (P - JOFF); copy (i0 & 3) makes the start 8-byte aligned -> two ds_read_b64.
+constexpr int NCOPY = 4;
+constexpr int packed_elems(int K) { return NCOPY * K * WPAD; }
+
+template <int K, int P, int JOFF>
+__device__ __forceinline__ bf16x8 load_bfrag(const uint16_t* img, int ky, int s, int lane) {
+    const int i0 = 32 + 32 * s + 8 * (lane >> 4) - (lane & 15) + (P - JOFF);
+    const int copy = i0 & 3;
+    const uint2* p = reinterpret_cast<const uint2*>(img + (copy * K + ky) * WPAD + (i0 - copy));
+    const uint2 lo = p[0], hi = p[1];
+    return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
 }
 
-// Stage the padded filter image of channel c (flipped for dgrad): wimg[copy][ky][WPAD].
-template <int K>
-__device__ __forceinline__ void stage_filter(uint16_t* wimg, const float* __restrict__ w, bool flip, int tid,
-                                             int nthreads) {
-    for (int i = tid; i < 2 * K * WPAD; i += nthreads) {
-        const int copy = i / (K * WPAD);
-        const int r = i - copy * K * WPAD;
-        const int ky = r / WPAD, col = r - ky * WPAD;
-        const int t = col + copy - 32;                        // odd copy is shifted left by one
+__global__ void pack_filter_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int C, int K, int flip) {
+    const long total = (long)C * NCOPY * K * WPAD;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int col = (int)(i % WPAD);
+        const int ky = (int)((i / WPAD) % K);
+        const int copy = (int)((i / ((long)WPAD * K)) % NCOPY);
+        const int c = (int)(i / ((long)WPAD * K * NCOPY));
+        const int t = col + copy - 32;
         float v = 0.f;
-        if (t >= 0 && t < K) v = flip ? w[(K - 1 - ky) * K + (K - 1 - t)] : w[ky * K + t];
-        wimg[i] = f32_to_bf16(v);
+        if (t >= 0 && t < K)
+            v = flip ? w[((long)c * K + (K - 1 - ky)) * K + (K - 1 - t)] : w[((long)c * K + ky) * K + t];
+        out[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
     }
+}
+
+// Copy a channel's packed image (16-byte granules) into the wave's LDS region.
+__device__ __forceinline__ void copy_image(uint8_t* dst, const uint16_t* __restrict__ src, int elems, int lane) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (int i = lane; i < elems / 8; i += WAVE) d4[i] = s4[i];
 }
 
 struct Item {
@@ -236,8 +245,8 @@ __device__ __forceinline__ void store_tile(uint16_t* __restrict__ dst, const f32
 // MODE 1: dgrad (in0 = dy_big, in1 = dy_small if KS; out0 = dx), filters flipped
 template <int K, int KS, int MODE, int NSEG>
 __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
-    const uint16_t* __restrict__ in0, const uint16_t* __restrict__ in1, const float* __restrict__ w_big,
-    const float* __restrict__ w_small, uint16_t* __restrict__ out0, uint16_t* __restrict__ out1, int N, int C,
+    const uint16_t* __restrict__ in0, const uint16_t* __restrict__ in1, const uint16_t* __restrict__ w_big,
+    const uint16_t* __restrict__ w_small, uint16_t* __restrict__ out0, uint16_t* __restrict__ out1, int N, int C,
     int H, int W, int G, int band, int bands, int segs, int items_per_channel, int ipw, int wpc,
     long total_waves, int tile_bytes, int region_bytes) {
     using GE = Geo<K>;
@@ -246,37 +255,28 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
     constexpr int AGPR_FROM = 6;             // big-filter fragments [AGPR_FROM, K*NS) live in AGPRs
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // One LDS region per wave: first the padded filter image of the wave's channel (needed only while
-    // the Toeplitz fragments are built), then overlaid by the wave's input tile(s).
+    // One LDS region per wave: first the packed filter image of the wave's channel (needed only while
+    // the Toeplitz fragments are built), then overlaid by the wave's input tile(s).  Nothing is shared
+    // between waves, so the kernel has no workgroup barrier.
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const long wid0 = (long)blockIdx.x * WAVES;
-    // filter images of the workgroup's (up to) four channels, staged by all 256 threads
-#pragma unroll 1
-    for (int w = 0; w < WAVES; ++w) {
-        const long wid = wid0 + w;
-        if (wid >= total_waves) break;
-        const int cw = (int)(wid / wpc);
-        uint16_t* img = reinterpret_cast<uint16_t*>(smem + (long)w * region_bytes);
-        stage_filter<K>(img, w_big + (long)cw * K * K, MODE == 1, threadIdx.x, 64 * WAVES);
-        if constexpr (KS > 0)
-            stage_filter<KS>(img + 2 * K * WPAD, w_small + (long)cw * KS * KS, MODE == 1, threadIdx.x, 64 * WAVES);
-    }
-    __syncthreads();
-    const long wid = wid0 + wave;
+    const long wid = (long)blockIdx.x * WAVES + wave;
     if (wid >= total_waves) return;
     const int c = (int)(wid / wpc);
     const int first_item = (int)(wid - (long)c * wpc) * ipw;
-    uint16_t* wimg_b = reinterpret_cast<uint16_t*>(smem + (long)wave * region_bytes);
-    uint16_t* wimg_s = wimg_b + 2 * K * WPAD;
+    uint8_t* region = smem + (long)wave * region_bytes;
+    copy_image(region, w_big + (long)c * packed_elems(K), packed_elems(K), lane);
+    if constexpr (KS > 0)
+        copy_image(region + packed_elems(K) * 2, w_small + (long)c * packed_elems(KS), packed_elems(KS), lane);
+    const uint16_t* wimg_b = reinterpret_cast<const uint16_t*>(region);
+    const uint16_t* wimg_s = wimg_b + packed_elems(K);
 
     // Toeplitz fragments of the whole filter: registers for the rest of the kernel
     bf16x8 bf_big[K][GE::NS];
 #pragma unroll
     for (int ky = 0; ky < K; ++ky)
 #pragma unroll
-        for (int s = 0; s < GE::NS; ++s)
-            bf_big[ky][s] = load_bfrag<GE::P, GE::JOFF>(wimg_b + ky * WPAD, wimg_b + (K + ky) * WPAD, s, lane);
+        for (int s = 0; s < GE::NS; ++s) bf_big[ky][s] = load_bfrag<K, GE::P, GE::JOFF>(wimg_b, ky, s, lane);
     // Park most Toeplitz fragments in the accumulator half of the unified register file (MFMA reads its
     // B operand from AGPRs directly); this keeps the arch VGPRs free for A-fragment prefetch.
 #pragma unroll
@@ -287,8 +287,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     bf16x8 bf_small[(KS > 0 ? KS : 1)][1];
     if constexpr (KS > 0) {
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky)
-            bf_small[ky][0] = load_bfrag<GS::P, GS::JOFF>(wimg_s + ky * WPAD, wimg_s + (KS + ky) * WPAD, 0, lane);
+        for (int ky = 0; ky < KS; ++ky) bf_small[ky][0] = load_bfrag<KS, GS::P, GS::JOFF>(wimg_s, ky, 0, lane);
     }
     // the fragment reads above must have completed before the tile staging overwrites the image
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -357,11 +356,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
 }
 
 template <int K, int KS, int MODE, int NSEG>
-int launch(const uint16_t* in0, const uint16_t* in1, const float* wb, const float* ws, uint16_t* o0,
+int launch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0,
            uint16_t* o1, int N, int C, int H, int W, hipStream_t st) {
     constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
     constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
-    constexpr int FILT_BYTES = ((2 * K * WPAD + 2 * KS * WPAD) * 2 + 15) & ~15;
+    constexpr int FILT_BYTES = (packed_elems(K) + (KS > 0 ? packed_elems(KS) : 0)) * 2;
     if ((long)N * C * H * W >= (1L << 31)) return PPEA_ERR_UNSUPPORTED;      // 32-bit element offsets
     // largest band / stacking whose per-wave region fits four times into the 160 KB of LDS
     int band = 0, G = 1, tile_bytes = 0, region = 0;
@@ -410,7 +409,7 @@ inline long staged_cols(int W, int nseg) {
 }
 
 template <int K, int KS, int MODE>
-int launch_k(const uint16_t* in0, const uint16_t* in1, const float* wb, const float* ws, uint16_t* o0,
+int launch_k(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0,
              uint16_t* o1, int N, int C, int H, int W, hipStream_t st) {
     const long c5 = staged_cols<K>(W, 5), c3 = staged_cols<K>(W, 3), c2 = staged_cols<K>(W, 2);
     if (c5 <= c3 && c5 <= c2) return launch<K, KS, MODE, 5>(in0, in1, wb, ws, o0, o1, N, C, H, W, st);
@@ -419,7 +418,7 @@ int launch_k(const uint16_t* in0, const uint16_t* in1, const float* wb, const fl
 }
 
 template <int MODE>
-int dispatch(const uint16_t* in0, const uint16_t* in1, const float* wb, const float* ws, uint16_t* o0,
+int dispatch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0,
              uint16_t* o1, int N, int C, int H, int W, int K, int KS, hipStream_t st) {
 #define PPEA_CASE(K_)                                                                             \
     case K_:                                                                                      \
@@ -434,14 +433,41 @@ int dispatch(const uint16_t* in0, const uint16_t* in1, const float* wb, const fl
 
 }  // namespace
 
-// Internal entry points used by dwconv_lk.hip's bf16 ABI functions (same shared object).
-int ppea_internal_dwconv_mfma_fwd(const uint16_t* x, const float* wb, const float* ws, uint16_t* yb,
-                                  uint16_t* ys, int N, int C, int H, int W, int K, int KS, void* stream) {
-    if (N <= 0 || (KS != 0 && KS != 5)) return PPEA_ERR_UNSUPPORTED;
-    return dispatch<0>(x, nullptr, wb, ws, yb, ys, N, C, H, W, K, KS, (hipStream_t)stream);
+extern "C" {
+
+long ppea_dwconv_lk_packed_bytes(int C, int K) {
+    if (C <= 0 || K < 3 || K > 31 || (K & 1) == 0) return -1;
+    return (long)C * packed_elems(K) * 2;
 }
-int ppea_internal_dwconv_mfma_bwd(const uint16_t* dyb, const uint16_t* dys, const float* wb, const float* ws,
-                                  uint16_t* dx, int N, int C, int H, int W, int K, int KS, void* stream) {
-    if (N <= 0 || (KS != 0 && KS != 5)) return PPEA_ERR_UNSUPPORTED;
-    return dispatch<1>(dyb, dys, wb, ws, dx, nullptr, N, C, H, W, K, KS, (hipStream_t)stream);
+
+int ppea_dwconv_lk_pack_bf16(const float* w, void* packed, int C, int K, int flip, void* stream) {
+    if (C <= 0 || K < 3 || K > 31 || (K & 1) == 0) return PPEA_ERR_UNSUPPORTED;
+    const long total = (long)C * packed_elems(K);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_filter_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w,
+                       (uint16_t*)packed, C, K, flip);
+    return launch_status();
 }
+
+int ppea_dwconv_lk_fwd_bf16p(const uint16_t* x, const void* packed_big, const void* packed_small, uint16_t* y_big,
+                             uint16_t* y_small, int N, int C, int H, int W, int K, int KS, void* stream) {
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0) return PPEA_ERR_UNSUPPORTED;
+    if (N == 0) return 0;
+    if (packed_small == nullptr || y_small == nullptr) KS = 0;
+    if (KS != 0 && KS != 5) return PPEA_ERR_UNSUPPORTED;
+    return dispatch<0>(x, nullptr, (const uint16_t*)packed_big, (const uint16_t*)packed_small, y_big, y_small, N, C,
+                       H, W, K, KS, (hipStream_t)stream);
+}
+
+int ppea_dwconv_lk_bwd_data_bf16p(const uint16_t* dy_big, const uint16_t* dy_small, const void* packed_big_flip,
+                                  const void* packed_small_flip, uint16_t* dx, int N, int C, int H, int W, int K,
+                                  int KS, void* stream) {
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0) return PPEA_ERR_UNSUPPORTED;
+    if (N == 0) return 0;
+    if (packed_small_flip == nullptr || dy_small == nullptr) KS = 0;
+    if (KS != 0 && KS != 5) return PPEA_ERR_UNSUPPORTED;
+    return dispatch<1>(dy_big, dy_small, (const uint16_t*)packed_big_flip, (const uint16_t*)packed_small_flip, dx,
+                       nullptr, N, C, H, W, K, KS, (hipStream_t)stream);
+}
+
+}  // extern "C"

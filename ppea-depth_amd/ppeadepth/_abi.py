@@ -24,6 +24,10 @@ SIGNATURES = {
     "ppea_dwconv_lk_bwd_data_f32": [_vp] * 5 + [_i] * 6 + [_vp],
     "ppea_dwconv_lk_bwd_data_bf16": [_vp] * 5 + [_i] * 6 + [_vp],
     "ppea_dwconv_lk_bwd_filter_f32": [_vp] * 3 + [_i] * 5 + [_vp],
+    "ppea_dwconv_lk_packed_bytes": [_i, _i],
+    "ppea_dwconv_lk_pack_bf16": [_vp, _vp, _i, _i, _i, _vp],
+    "ppea_dwconv_lk_fwd_bf16p": [_vp] * 5 + [_i] * 6 + [_vp],
+    "ppea_dwconv_lk_bwd_data_bf16p": [_vp] * 5 + [_i] * 6 + [_vp],
     "ppea_backproject_project_fwd_f32": [_vp] * 4 + [_i] * 3 + [_f, _vp],
     "ppea_backproject_project_bwd_f32": [_vp] * 6 + [_i] * 3 + [_f, _vp],
     "ppea_grid_sample_fwd_f32": [_vp] * 3 + [_i] * 7 + [_vp],
@@ -49,7 +53,7 @@ def _load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_long if name.endswith("_bytes") else ctypes.c_int
     got = lib.ppea_abi_version()
     if got != ABI_VERSION:
         raise ImportError(f"libppea_depth.so ABI {got} != expected {ABI_VERSION}: rebuild")

@@ -36,6 +36,33 @@ def _suffix(t):
 
 
 # ---------------------------------------------------------------------------------------------
+# packed bf16 filter images for the MFMA depthwise kernel, cached per (weight storage, version, flip)
+# ---------------------------------------------------------------------------------------------
+_PACK_CACHE = {}
+_MFMA_K = (31, 29, 27, 13)
+
+
+def _packed_filter(w, flip):
+    """uint8 buffer with the bf16 Toeplitz source image of w [C,1,K,K]; rebuilt when w changes in place."""
+    key = (w.data_ptr(), w.device.index, int(flip))
+    ver = w._version
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[2] == tuple(w.shape):
+        return hit[1]
+    C, K = w.shape[0], w.shape[-1]
+    nbytes = _abi.lib.ppea_dwconv_lk_packed_bytes(C, K)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    wf = w.detach().to(_F32).contiguous()
+    call("ppea_dwconv_lk_pack_bf16", ptr(wf), ptr(buf), C, K, int(flip), stream_ptr())
+    _PACK_CACHE[key] = (ver, buf, tuple(w.shape))
+    return buf
+
+
+def _mfma_ok(x, K, KS):
+    return x.dtype == _BF16 and K in _MFMA_K and KS in (0, 5)
+
+
+# ---------------------------------------------------------------------------------------------
 # A1  large-kernel depthwise conv (+ fused 5x5 branch)   networks/replknet_adapter.py:151-168, 232-239
 # ---------------------------------------------------------------------------------------------
 class _DwConvLK(torch.autograd.Function):
@@ -49,8 +76,21 @@ class _DwConvLK(torch.autograd.Function):
         ws = None if w_small is None else w_small.detach().to(_F32).contiguous()
         y_big = torch.empty_like(x)
         y_small = torch.empty_like(x) if KS else None
-        _timed("fwd31", K, lambda: call(f"ppea_dwconv_lk_fwd_{_suffix(x)}", ptr(x), ptr(wb, _F32), ptr(ws),
-                                         ptr(y_big), ptr(y_small), N, C, H, W, K, KS, stream_ptr()))
+        ctx.packed = None
+        done = False
+        if _mfma_ok(x, K, KS):
+            pb = _packed_filter(w_big, False)
+            ps = _packed_filter(w_small, False) if KS else None
+            err = _timed("fwd31", K, lambda: _abi.lib.ppea_dwconv_lk_fwd_bf16p(
+                ptr(x), ptr(pb), ptr(ps), ptr(y_big), ptr(y_small), N, C, H, W, K, KS, stream_ptr()))
+            if err == 0:
+                done = True
+                ctx.packed = (w_big, w_small)
+            elif err != -1:
+                _abi.check(err, "ppea_dwconv_lk_fwd_bf16p")
+        if not done:
+            _timed("fwd31", K, lambda: call(f"ppea_dwconv_lk_fwd_{_suffix(x)}", ptr(x), ptr(wb, _F32), ptr(ws),
+                                             ptr(y_big), ptr(y_small), N, C, H, W, K, KS, stream_ptr()))
         ctx.save_for_backward(x, wb, ws)
         ctx.has_small = KS > 0
         ctx.w_dtypes = (w_big.dtype, None if w_small is None else w_small.dtype)
@@ -74,8 +114,20 @@ class _DwConvLK(torch.autograd.Function):
             dy_small = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _timed("bwd31", K, lambda: call(f"ppea_dwconv_lk_bwd_data_{_suffix(x)}", ptr(dy_big), ptr(dy_small),
-                                             ptr(wb), ptr(ws), ptr(dx), N, C, H, W, K, KS, stream_ptr()))
+            done = False
+            if ctx.packed is not None:
+                pb = _packed_filter(ctx.packed[0], True)
+                ps = _packed_filter(ctx.packed[1], True) if KS else None
+                err = _timed("bwd31", K, lambda: _abi.lib.ppea_dwconv_lk_bwd_data_bf16p(
+                    ptr(dy_big), ptr(dy_small), ptr(pb), ptr(ps), ptr(dx), N, C, H, W, K, KS, stream_ptr()))
+                if err == 0:
+                    done = True
+                elif err != -1:
+                    _abi.check(err, "ppea_dwconv_lk_bwd_data_bf16p")
+            if not done:
+                _timed("bwd31", K, lambda: call(f"ppea_dwconv_lk_bwd_data_{_suffix(x)}", ptr(dy_big),
+                                                 ptr(dy_small), ptr(wb), ptr(ws), ptr(dx), N, C, H, W, K, KS,
+                                                 stream_ptr()))
         if ctx.needs_input_grad[1]:
             dwb = torch.empty_like(wb)
             call("ppea_dwconv_lk_bwd_filter_f32", ptr(x.float().contiguous()), ptr(dy_big.float().contiguous()),

@@ -17,14 +17,14 @@ from conftest import GOLDEN, ROOT, rel_err
 def test_abi_exports_every_declared_symbol():
     from ppeadepth import _abi
     header = open(os.path.join(ROOT, "include", "ppea_depth.h")).read()
-    declared = set(re.findall(r"^int\s+(ppea_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|long)\s+(ppea_\w+)\s*\(", header, flags=re.M))
     assert declared, "no declarations parsed"
     assert declared == set(_abi.SIGNATURES), declared ^ set(_abi.SIGNATURES)
     for name in declared:
         assert hasattr(_abi.lib, name), name
     assert _abi.lib.ppea_abi_version() == _abi.ABI_VERSION
     # argument counts in the header match the ctypes signatures
-    for m in re.finditer(r"^int\s+(ppea_\w+)\s*\(([^;]*?)\);", header, flags=re.M | re.S):
+    for m in re.finditer(r"^(?:int|long)\s+(ppea_\w+)\s*\(([^;]*?)\);", header, flags=re.M | re.S):
         name, args = m.group(1), m.group(2).strip()
         n = 0 if args in ("void", "") else len([a for a in args.split(",") if a.strip()])
         assert n == len(_abi.SIGNATURES[name]), (name, n, len(_abi.SIGNATURES[name]))
