@@ -74,6 +74,46 @@ int ppea_dwconv_lk_bwd_filter_f32(const float* x, const float* dy, float* dw,
                                   int N, int C, int H, int W, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * A2 (+A5/A6 glue)  Training-mode BatchNorm fused with its neighbours (csrc/bn_fused.hip):
+ *     y = act( BN_a(z1) [+ BN_b(z2)] ) [* mask[n]] [+ r1] [+ r2_scale * r2]
+ *   replaces conv_bn / conv_bn_relu (replknet_adapter.py:182-197), the two-branch sum of
+ *   ReparamLargeKernelConv.forward (:232-239) and the residual / DropPath / adapter adds of
+ *   RepLKBlock.forward (:315-326) and ConvFFN.forward (:283-289).  NCHW, HW = H*W.
+ *   act: 0 none, 1 ReLU, 2 GELU(erf).  z2, mask [N], r1, r2 may be NULL.
+ *   stats = host array of 8 DEVICE pointers {mean1, invstd1, gamma1, beta1, mean2, invstd2, gamma2, beta2}.
+ *   forward : ppea_bn_stats_*   per-plane (mean, M2) -> partial [C][N][2]
+ *             ppea_bn_finalize_f32  Chan-combine -> mean/var(biased)/invstd [C]; running stats updated
+ *                                   (momentum, unbiased var) unless running_mean is NULL
+ *             ppea_bn_apply_*
+ *   backward: g = dy * mask[n] * act'(u);
+ *             ppea_bn_bwd_reduce_*  -> partial [C][N][3] = sum g, sum g*zhat1, sum g*zhat2
+ *             ppea_bn_bwd_finalize_f32 -> sums [3][C]  (d_beta = sums[0], d_gamma_k = sums[k])
+ *             ppea_bn_bwd_apply_*   dz_k = gamma_k*invstd_k*(g - sums0*inv_count - zhat_k*sums_k*inv_count)
+ * ---------------------------------------------------------------------------------------- */
+int ppea_bn_stats_f32(const void* z, float* partial, int N, int C, int HW, void* stream);
+int ppea_bn_stats_bf16(const void* z, float* partial, int N, int C, int HW, void* stream);
+int ppea_bn_finalize_f32(const float* partial, int N, int C, int HW, float eps, float momentum,
+                         float* mean, float* var, float* invstd, float* running_mean,
+                         float* running_var, void* stream);
+int ppea_bn_apply_f32(const void* z1, const void* z2, const float* const* stats, const float* mask,
+                      const void* r1, const void* r2, float r2_scale, void* y, int act,
+                      int N, int C, int HW, void* stream);
+int ppea_bn_apply_bf16(const void* z1, const void* z2, const float* const* stats, const float* mask,
+                       const void* r1, const void* r2, float r2_scale, void* y, int act,
+                       int N, int C, int HW, void* stream);
+int ppea_bn_bwd_reduce_f32(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                           const float* mask, float* partial, int act, int N, int C, int HW, void* stream);
+int ppea_bn_bwd_reduce_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                            const float* mask, float* partial, int act, int N, int C, int HW, void* stream);
+int ppea_bn_bwd_finalize_f32(const float* partial, int N, int C, float* sums, void* stream);
+int ppea_bn_bwd_apply_f32(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                          const float* mask, const float* sums, float inv_count, void* dz1, void* dz2,
+                          int act, int N, int C, int HW, void* stream);
+int ppea_bn_bwd_apply_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                           const float* mask, const float* sums, float inv_count, void* dz1, void* dz2,
+                           int act, int N, int C, int HW, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * A18+A19  BackprojectDepth -> Project3D fused (layers.py:138-199; trainer.py:904-907).
  *     depth [B,1,H,W]; inv_K [B,4,4] (only [:3,:3] read); P [B,3,4] = (K @ T)[:, :3, :];
  *     grid [B,H,W,2] normalised to [-1,1] (x then y); eps added to z (1e-7).

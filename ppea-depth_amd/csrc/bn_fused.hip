@@ -1,0 +1,392 @@
+// Training-mode batch norm fused with its neighbours, gfx950 (HBM-bound; every tensor crosses HBM once
+// per kernel).  Replaces, per call site of networks/replknet_adapter.py (conv_bn / conv_bn_relu :182-197,
+// ReparamLargeKernelConv.forward :232-239, RepLKBlock.forward :315-326, ConvFFN.forward :283-289):
+//     y = act( BN_a(z1) [+ BN_b(z2)] ) [* mask[n]] [+ r1] [+ s * r2]
+// i.e. batch-norm (batch statistics), the optional second re-param branch, ReLU / GELU, the DropPath
+// per-sample scale, the residual and the adapter branch -- 6-8 ATen kernels -- in
+//   forward : bn_stats (per-plane mean / M2)  ->  bn_finalize (per channel, updates running stats)
+//             -> bn_apply (one elementwise pass);
+//   backward: bn_bwd_reduce (per-plane sums of g and g*zhat) -> bn_bwd_finalize -> bn_bwd_apply.
+// Statistics are combined with Chan's parallel-variance formula (per-plane two-pass sums), so there
+// is no E[x^2] - mean^2 cancellation.  Layout NCHW, T = float or bf16 (fp32 math).
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int V = 8;         // elements per thread per step on the 16-byte path
+
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&o)[V]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o)[V]) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8<uint16_t>(const uint16_t* p, float (&o)[V]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        o[2 * k] = __uint_as_float(w[k] << 16);
+        o[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+    }
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[V]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[V]) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void st8<uint16_t>(uint16_t* p, const float (&v)[V]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t lo = __builtin_bit_cast(uint16_t, (__bf16)v[2 * k]);
+        const uint32_t hi = __builtin_bit_cast(uint16_t, (__bf16)v[2 * k + 1]);
+        w[k] = lo | (hi << 16);
+    }
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// partial[(c*N + n)*2 + {0,1}] = (mean, M2) of plane (n, c)
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_stats(const T* __restrict__ z, float* __restrict__ partial, int N, int C,
+                                                int HW) {
+    __shared__ float red[4];
+    const int n = blockIdx.x / C, c = blockIdx.x - n * C;
+    const T* p = z + (long)blockIdx.x * HW;
+    const int hv = ((HW % V) == 0) ? HW : 0;            // 16-byte path needs aligned planes
+    float s = 0.f;
+    for (int i = threadIdx.x * V; i < hv; i += TPB * V) {
+        float x[V];
+        ld8<T>(p + i, x);
+#pragma unroll
+        for (int k = 0; k < V; ++k) s += x[k];
+    }
+    for (int i = hv + threadIdx.x; i < HW; i += TPB) s += ld_f32<T>(p + i);
+    const float mean = block_sum(s, red) / (float)HW;
+    float m2 = 0.f;
+    for (int i = threadIdx.x * V; i < hv; i += TPB * V) {
+        float x[V];
+        ld8<T>(p + i, x);
+#pragma unroll
+        for (int k = 0; k < V; ++k) m2 += (x[k] - mean) * (x[k] - mean);
+    }
+    for (int i = hv + threadIdx.x; i < HW; i += TPB) {
+        const float d = ld_f32<T>(p + i) - mean;
+        m2 += d * d;
+    }
+    m2 = block_sum(m2, red);
+    if (threadIdx.x == 0) {
+        partial[((long)c * N + n) * 2] = mean;
+        partial[((long)c * N + n) * 2 + 1] = m2;
+    }
+}
+
+__global__ void bn_finalize(const float* __restrict__ partial, int N, int C, int HW, float eps, float momentum,
+                            float* __restrict__ mean_out, float* __restrict__ var_out, float* __restrict__ invstd_out,
+                            float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* p = partial + (long)c * N * 2;
+    float mean = 0.f;
+    for (int n = 0; n < N; ++n) mean += p[2 * n];
+    mean /= (float)N;
+    float m2 = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float d = p[2 * n] - mean;
+        m2 += p[2 * n + 1] + (float)HW * d * d;
+    }
+    const float cnt = (float)N * (float)HW;
+    const float var = m2 / cnt;
+    mean_out[c] = mean;
+    var_out[c] = var;
+    invstd_out[c] = rsqrtf(var + eps);
+    if (running_mean != nullptr) {
+        const float unbiased = m2 / fmaxf(cnt - 1.f, 1.f);
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+struct Branch {
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+};
+
+__device__ __forceinline__ float act_fwd(float u, int act) {
+    if (act == 1) return fmaxf(u, 0.f);
+    if (act == 2) return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
+    return u;
+}
+__device__ __forceinline__ float act_bwd(float u, int act) {
+    if (act == 1) return u > 0.f ? 1.f : 0.f;
+    if (act == 2) {
+        const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
+        const float pdf = 0.39894228040143268f * expf(-0.5f * u * u);
+        return cdf + u * pdf;
+    }
+    return 1.f;
+}
+
+// one block per (plane, chunk); VEC elements per thread per iteration
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_apply(const T* __restrict__ z1, const T* __restrict__ z2, Branch b1,
+                                                Branch b2, const float* __restrict__ mask, const T* __restrict__ r1,
+                                                const T* __restrict__ r2, float r2_scale, T* __restrict__ y, int act,
+                                                int C, int HW, int chunks) {
+    const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
+    const int n = plane / C, c = plane - n * C;
+    const float a1 = b1.gamma[c] * b1.invstd[c], o1 = b1.beta[c] - b1.mean[c] * a1;
+    float a2 = 0.f, o2 = 0.f;
+    if (z2 != nullptr) { a2 = b2.gamma[c] * b2.invstd[c]; o2 = b2.beta[c] - b2.mean[c] * a2; }
+    const float m = (mask != nullptr) ? mask[n] : 1.f;
+    const long base = (long)plane * HW;
+    const int per = (((HW + chunks - 1) / chunks) + V - 1) / V * V;
+    const int i0 = chunk * per, i1 = min(HW, i0 + per);
+    const int iv = ((HW % V) == 0) ? i1 : i0;
+    for (int i = i0 + threadIdx.x * V; i < iv; i += TPB * V) {
+        float x1[V], x2[V], q1[V], q2[V], o[V];
+        ld8<T>(z1 + base + i, x1);
+        if (z2 != nullptr) ld8<T>(z2 + base + i, x2);
+        if (r1 != nullptr) ld8<T>(r1 + base + i, q1);
+        if (r2 != nullptr) ld8<T>(r2 + base + i, q2);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float u = a1 * x1[k] + o1;
+            if (z2 != nullptr) u += a2 * x2[k] + o2;
+            float v = act_fwd(u, act) * m;
+            if (r1 != nullptr) v += q1[k];
+            if (r2 != nullptr) v += r2_scale * q2[k];
+            o[k] = v;
+        }
+        st8<T>(y + base + i, o);
+    }
+    for (int i = iv + threadIdx.x; i < i1; i += TPB) {
+        float u = a1 * ld_f32<T>(z1 + base + i) + o1;
+        if (z2 != nullptr) u += a2 * ld_f32<T>(z2 + base + i) + o2;
+        float v = act_fwd(u, act) * m;
+        if (r1 != nullptr) v += ld_f32<T>(r1 + base + i);
+        if (r2 != nullptr) v += r2_scale * ld_f32<T>(r2 + base + i);
+        st_f32<T>(y + base + i, v);
+    }
+}
+
+// partial[(c*N + n)*3 + {0,1,2}] = sum g, sum g*zhat1, sum g*zhat2   with g = dy * mask[n] * act'(u)
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce(const T* __restrict__ dy, const T* __restrict__ z1,
+                                                     const T* __restrict__ z2, Branch b1, Branch b2,
+                                                     const float* __restrict__ mask, float* __restrict__ partial,
+                                                     int act, int N, int C, int HW) {
+    __shared__ float red[4];
+    const int n = blockIdx.x / C, c = blockIdx.x - n * C;
+    const float is1 = b1.invstd[c], mu1 = b1.mean[c];
+    const float a1 = b1.gamma[c] * is1, o1 = b1.beta[c] - mu1 * a1;
+    float is2 = 0.f, mu2 = 0.f, a2 = 0.f, o2 = 0.f;
+    if (z2 != nullptr) { is2 = b2.invstd[c]; mu2 = b2.mean[c]; a2 = b2.gamma[c] * is2; o2 = b2.beta[c] - mu2 * a2; }
+    const float m = (mask != nullptr) ? mask[n] : 1.f;
+    const long base = (long)blockIdx.x * HW;
+    float sg = 0.f, s1 = 0.f, s2 = 0.f;
+    const int hv = ((HW % V) == 0) ? HW : 0;
+    for (int i = threadIdx.x * V; i < hv; i += TPB * V) {
+        float x1[V], x2[V], d[V];
+        ld8<T>(z1 + base + i, x1);
+        if (z2 != nullptr) ld8<T>(z2 + base + i, x2);
+        ld8<T>(dy + base + i, d);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float u = a1 * x1[k] + o1;
+            float xx2 = 0.f;
+            if (z2 != nullptr) { xx2 = x2[k]; u += a2 * xx2 + o2; }
+            const float g = d[k] * m * act_bwd(u, act);
+            sg += g;
+            s1 += g * (x1[k] - mu1) * is1;
+            s2 += g * (xx2 - mu2) * is2;
+        }
+    }
+    for (int i = hv + threadIdx.x; i < HW; i += TPB) {
+        const float x1 = ld_f32<T>(z1 + base + i);
+        float u = a1 * x1 + o1;
+        float x2 = 0.f;
+        if (z2 != nullptr) { x2 = ld_f32<T>(z2 + base + i); u += a2 * x2 + o2; }
+        const float g = ld_f32<T>(dy + base + i) * m * act_bwd(u, act);
+        sg += g;
+        s1 += g * (x1 - mu1) * is1;
+        s2 += g * (x2 - mu2) * is2;
+    }
+    sg = block_sum(sg, red);
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        float* p = partial + ((long)c * N + n) * 3;
+        p[0] = sg; p[1] = s1; p[2] = s2;
+    }
+}
+
+// sums[0*C + c] = sum g, sums[1*C + c] = sum g*zhat1, sums[2*C + c] = sum g*zhat2
+__global__ void bn_bwd_finalize(const float* __restrict__ partial, int N, int C, float* __restrict__ sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* p = partial + (long)c * N * 3;
+    float a = 0.f, b = 0.f, d = 0.f;
+    for (int n = 0; n < N; ++n) { a += p[3 * n]; b += p[3 * n + 1]; d += p[3 * n + 2]; }
+    sums[c] = a; sums[C + c] = b; sums[2 * C + c] = d;
+}
+
+// dz_k = gamma_k * invstd_k * (g - sum_g / M - zhat_k * sum_gz_k / M),  M = count (global batch)
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_bwd_apply(const T* __restrict__ dy, const T* __restrict__ z1,
+                                                    const T* __restrict__ z2, Branch b1, Branch b2,
+                                                    const float* __restrict__ mask, const float* __restrict__ sums,
+                                                    float inv_count, T* __restrict__ dz1, T* __restrict__ dz2,
+                                                    int act, int C, int HW, int chunks) {
+    const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
+    const int n = plane / C, c = plane - n * C;
+    const float is1 = b1.invstd[c], mu1 = b1.mean[c];
+    const float a1 = b1.gamma[c] * is1, o1 = b1.beta[c] - mu1 * a1;
+    float is2 = 0.f, mu2 = 0.f, a2 = 0.f, o2 = 0.f;
+    if (z2 != nullptr) { is2 = b2.invstd[c]; mu2 = b2.mean[c]; a2 = b2.gamma[c] * is2; o2 = b2.beta[c] - mu2 * a2; }
+    const float m = (mask != nullptr) ? mask[n] : 1.f;
+    const float mg = sums[c] * inv_count, m1 = sums[C + c] * inv_count, m2 = sums[2 * C + c] * inv_count;
+    const long base = (long)plane * HW;
+    const int per = (((HW + chunks - 1) / chunks) + V - 1) / V * V;
+    const int i0 = chunk * per, i1 = min(HW, i0 + per);
+    const int iv = ((HW % V) == 0) ? i1 : i0;
+    for (int i = i0 + threadIdx.x * V; i < iv; i += TPB * V) {
+        float x1[V], x2[V], d[V], o1v[V], o2v[V];
+        ld8<T>(z1 + base + i, x1);
+        if (z2 != nullptr) ld8<T>(z2 + base + i, x2);
+        ld8<T>(dy + base + i, d);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float u = a1 * x1[k] + o1;
+            float xx2 = 0.f;
+            if (z2 != nullptr) { xx2 = x2[k]; u += a2 * xx2 + o2; }
+            const float g = d[k] * m * act_bwd(u, act);
+            o1v[k] = a1 * (g - mg - (x1[k] - mu1) * is1 * m1);
+            o2v[k] = a2 * (g - mg - (xx2 - mu2) * is2 * m2);
+        }
+        st8<T>(dz1 + base + i, o1v);
+        if (z2 != nullptr) st8<T>(dz2 + base + i, o2v);
+    }
+    for (int i = iv + threadIdx.x; i < i1; i += TPB) {
+        const float x1 = ld_f32<T>(z1 + base + i);
+        float u = a1 * x1 + o1;
+        float x2 = 0.f;
+        if (z2 != nullptr) { x2 = ld_f32<T>(z2 + base + i); u += a2 * x2 + o2; }
+        const float g = ld_f32<T>(dy + base + i) * m * act_bwd(u, act);
+        st_f32<T>(dz1 + base + i, a1 * (g - mg - (x1 - mu1) * is1 * m1));
+        if (z2 != nullptr) st_f32<T>(dz2 + base + i, a2 * (g - mg - (x2 - mu2) * is2 * m2));
+    }
+}
+
+inline int plane_chunks(long planes, int HW) {
+    // enough blocks to fill the chip (>= ~2048) without making them tiny
+    int chunks = 1;
+    while (planes * chunks < 2048 && HW / (chunks * 2) >= 1024) chunks *= 2;
+    return chunks;
+}
+
+template <typename T>
+int stats_impl(const void* z, float* partial, int N, int C, int HW, void* stream) {
+    if (N <= 0 || C <= 0 || HW <= 0) return PPEA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_stats<T>, dim3((unsigned)((long)N * C)), dim3(TPB), 0, (hipStream_t)stream, (const T*)z,
+                       partial, N, C, HW);
+    return launch_status();
+}
+
+template <typename T>
+int apply_impl(const void* z1, const void* z2, const float* const* st, const float* mask, const void* r1,
+               const void* r2, float r2_scale, void* y, int act, int N, int C, int HW, void* stream) {
+    if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return PPEA_ERR_UNSUPPORTED;
+    const Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
+    const int chunks = plane_chunks((long)N * C, HW);
+    hipLaunchKernelGGL(bn_apply<T>, dim3((unsigned)((long)N * C * chunks)), dim3(TPB), 0, (hipStream_t)stream,
+                       (const T*)z1, (const T*)z2, b1, b2, mask, (const T*)r1, (const T*)r2, r2_scale, (T*)y, act, C,
+                       HW, chunks);
+    return launch_status();
+}
+
+template <typename T>
+int bwd_reduce_impl(const void* dy, const void* z1, const void* z2, const float* const* st, const float* mask,
+                    float* partial, int act, int N, int C, int HW, void* stream) {
+    if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return PPEA_ERR_UNSUPPORTED;
+    const Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
+    hipLaunchKernelGGL(bn_bwd_reduce<T>, dim3((unsigned)((long)N * C)), dim3(TPB), 0, (hipStream_t)stream,
+                       (const T*)dy, (const T*)z1, (const T*)z2, b1, b2, mask, partial, act, N, C, HW);
+    return launch_status();
+}
+
+template <typename T>
+int bwd_apply_impl(const void* dy, const void* z1, const void* z2, const float* const* st, const float* mask,
+                   const float* sums, float inv_count, void* dz1, void* dz2, int act, int N, int C, int HW,
+                   void* stream) {
+    if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return PPEA_ERR_UNSUPPORTED;
+    const Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
+    const int chunks = plane_chunks((long)N * C, HW);
+    hipLaunchKernelGGL(bn_bwd_apply<T>, dim3((unsigned)((long)N * C * chunks)), dim3(TPB), 0, (hipStream_t)stream,
+                       (const T*)dy, (const T*)z1, (const T*)z2, b1, b2, mask, sums, inv_count, (T*)dz1, (T*)dz2, act,
+                       C, HW, chunks);
+    return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+// stats[8] = {mean1, invstd1, gamma1, beta1, mean2, invstd2, gamma2, beta2} (branch 2 NULL when z2 is NULL)
+int ppea_bn_stats_f32(const void* z, float* partial, int N, int C, int HW, void* stream) {
+    return stats_impl<float>(z, partial, N, C, HW, stream);
+}
+int ppea_bn_stats_bf16(const void* z, float* partial, int N, int C, int HW, void* stream) {
+    return stats_impl<uint16_t>(z, partial, N, C, HW, stream);
+}
+int ppea_bn_finalize_f32(const float* partial, int N, int C, int HW, float eps, float momentum, float* mean,
+                         float* var, float* invstd, float* running_mean, float* running_var, void* stream) {
+    if (N <= 0 || C <= 0 || HW <= 0) return PPEA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_finalize, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, N, C, HW, eps,
+                       momentum, mean, var, invstd, running_mean, running_var);
+    return launch_status();
+}
+int ppea_bn_apply_f32(const void* z1, const void* z2, const float* const* stats, const float* mask, const void* r1,
+                      const void* r2, float r2_scale, void* y, int act, int N, int C, int HW, void* stream) {
+    return apply_impl<float>(z1, z2, stats, mask, r1, r2, r2_scale, y, act, N, C, HW, stream);
+}
+int ppea_bn_apply_bf16(const void* z1, const void* z2, const float* const* stats, const float* mask, const void* r1,
+                       const void* r2, float r2_scale, void* y, int act, int N, int C, int HW, void* stream) {
+    return apply_impl<uint16_t>(z1, z2, stats, mask, r1, r2, r2_scale, y, act, N, C, HW, stream);
+}
+int ppea_bn_bwd_reduce_f32(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                           const float* mask, float* partial, int act, int N, int C, int HW, void* stream) {
+    return bwd_reduce_impl<float>(dy, z1, z2, stats, mask, partial, act, N, C, HW, stream);
+}
+int ppea_bn_bwd_reduce_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                            const float* mask, float* partial, int act, int N, int C, int HW, void* stream) {
+    return bwd_reduce_impl<uint16_t>(dy, z1, z2, stats, mask, partial, act, N, C, HW, stream);
+}
+int ppea_bn_bwd_finalize_f32(const float* partial, int N, int C, float* sums, void* stream) {
+    if (N <= 0 || C <= 0) return PPEA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, N, C, sums);
+    return launch_status();
+}
+int ppea_bn_bwd_apply_f32(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                          const float* mask, const float* sums, float inv_count, void* dz1, void* dz2, int act, int N,
+                          int C, int HW, void* stream) {
+    return bwd_apply_impl<float>(dy, z1, z2, stats, mask, sums, inv_count, dz1, dz2, act, N, C, HW, stream);
+}
+int ppea_bn_bwd_apply_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                           const float* mask, const float* sums, float inv_count, void* dz1, void* dz2, int act,
+                           int N, int C, int HW, void* stream) {
+    return bwd_apply_impl<uint16_t>(dy, z1, z2, stats, mask, sums, inv_count, dz1, dz2, act, N, C, HW, stream);
+}
+
+}  // extern "C"

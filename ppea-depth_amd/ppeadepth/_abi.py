@@ -28,6 +28,16 @@ SIGNATURES = {
     "ppea_dwconv_lk_pack_bf16": [_vp, _vp, _i, _i, _i, _vp],
     "ppea_dwconv_lk_fwd_bf16p": [_vp] * 5 + [_i] * 6 + [_vp],
     "ppea_dwconv_lk_bwd_data_bf16p": [_vp] * 5 + [_i] * 6 + [_vp],
+    "ppea_bn_stats_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "ppea_bn_stats_bf16": [_vp, _vp, _i, _i, _i, _vp],
+    "ppea_bn_finalize_f32": [_vp, _i, _i, _i, _f, _f] + [_vp] * 5 + [_vp],
+    "ppea_bn_apply_f32": [_vp] * 6 + [_f, _vp] + [_i] * 4 + [_vp],
+    "ppea_bn_apply_bf16": [_vp] * 6 + [_f, _vp] + [_i] * 4 + [_vp],
+    "ppea_bn_bwd_reduce_f32": [_vp] * 6 + [_i] * 4 + [_vp],
+    "ppea_bn_bwd_reduce_bf16": [_vp] * 6 + [_i] * 4 + [_vp],
+    "ppea_bn_bwd_finalize_f32": [_vp, _i, _i, _vp, _vp],
+    "ppea_bn_bwd_apply_f32": [_vp] * 6 + [_f, _vp, _vp] + [_i] * 4 + [_vp],
+    "ppea_bn_bwd_apply_bf16": [_vp] * 6 + [_f, _vp, _vp] + [_i] * 4 + [_vp],
     "ppea_backproject_project_fwd_f32": [_vp] * 4 + [_i] * 3 + [_f, _vp],
     "ppea_backproject_project_bwd_f32": [_vp] * 6 + [_i] * 3 + [_f, _vp],
     "ppea_grid_sample_fwd_f32": [_vp] * 3 + [_i] * 7 + [_vp],

@@ -109,6 +109,61 @@ class _SyncBNFn(torch.autograd.Function):
         return dx, gw, gb, None, None, None, None, None
 
 
+def _global_stats(bn, z):
+    """Batch statistics of z for `bn` in training mode: (mean, invstd, count, group).  One rank: two fused
+    launches (running stats updated in the second).  Several ranks (sync BN): local stats -> one packed
+    all-gather -> Chan combine; running stats updated with the global statistics."""
+    from . import ops
+    multi = bn.sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    cnt = z.numel() // z.shape[1]
+    if not multi:
+        mean, _var, invstd = ops.bn_batch_stats(z, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        return mean, invstd, float(cnt), None
+    mean_l, var_l, _ = ops.bn_batch_stats(z, bn.eps, bn.momentum, None, None)
+    C = mean_l.shape[0]
+    world = dist.get_world_size()
+    packed = torch.cat([mean_l, var_l, mean_l.new_full((1,), float(cnt))])
+    gathered = torch.empty(world, 2 * C + 1, device=z.device, dtype=packed.dtype)
+    dist.all_gather_into_tensor(gathered, packed)
+    means, vars_, counts = gathered[:, :C], gathered[:, C:2 * C], gathered[:, 2 * C:2 * C + 1]
+    total = counts.sum()
+    mean = (means * counts).sum(0) / total
+    m2 = ((vars_ + (means - mean) ** 2) * counts).sum(0)
+    var = m2 / total
+    invstd = torch.rsqrt(var + bn.eps)
+    with torch.no_grad():
+        bn.running_mean.lerp_(mean, bn.momentum)
+        bn.running_var.lerp_(m2 / (total - 1), bn.momentum)
+    return mean, invstd, float(cnt * world), (None,)
+
+
+def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None, r2_scale=1.0):
+    """act(BN1(z1) [+ BN2(z2)]) [* mask[n]] [+ r1] [+ r2_scale * r2] on the fused HIP kernels
+    (training mode: batch statistics, running stats and checkpoint-replay bookkeeping as BatchNorm2d)."""
+    from . import ops
+    assert bn1.training, "fused_bn_act is the training-mode path; eval goes through BatchNorm2d.forward"
+    bns = [(z1, bn1)] + ([(z2, bn2)] if z2 is not None else [])
+    stats = []
+    count, group = None, None
+    for z, bn in bns:
+        if bn.training:
+            mean, invstd, count, group = _global_stats(bn, z)
+            if _ACTIVE_DEFERRED is None:
+                bn.num_batches_tracked += 1
+            else:
+                _ACTIVE_DEFERRED.count(bn)
+                if bn.replay_update and torch.is_grad_enabled():
+                    _ACTIVE_DEFERRED.add(bn, mean, invstd, count)
+        else:
+            mean = bn.running_mean.float()
+            invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+        stats.append((mean, invstd))
+    m2, i2 = (stats[1] if z2 is not None else (None, None))
+    return ops.bn_act_apply(z1, bn1.weight, bn1.bias, stats[0][0], stats[0][1], z2,
+                            None if bn2 is None else bn2.weight, None if bn2 is None else bn2.bias, m2, i2,
+                            mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act, count=count, group=group)
+
+
 class BatchNorm2d(nn.Module):
     """Drop-in for nn.BatchNorm2d / nn.SyncBatchNorm (same parameters, buffers, state_dict keys)."""
 

@@ -14,7 +14,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops, rng
-from ..batchnorm import BatchNorm2d
+from ..batchnorm import BatchNorm2d, fused_bn_act
+
+FUSE_BN = True      # training-mode BN + activation + residual glue on the fused HIP kernels
 
 use_sync_bn = False
 
@@ -49,6 +51,15 @@ class DropPath(nn.Module):
         return f"drop_prob={self.drop_prob:.3f}"
 
 
+def _drop_mask(drop_path, x):
+    """Per-sample DropPath scale [N] (None for Identity / p = 0), drawn where the reference draws it."""
+    if not isinstance(drop_path, DropPath) or drop_path.drop_prob == 0.0 or not drop_path.training:
+        return None
+    keep = 1.0 - drop_path.drop_prob
+    m = rng.bernoulli_keep(x.shape[0], keep, x).reshape(-1).float()
+    return m / keep if keep > 0.0 else m
+
+
 class LargeKernelDW(nn.Conv2d):
     """Depthwise k x k conv (k > 5, stride 1, pad k//2) on the HIP kernel -- what `get_conv2d`
     returns through the LARGE_KERNEL_CONV_IMPL hook in the reference (rka.py:157-165)."""
@@ -71,10 +82,21 @@ def get_conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation
     return nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
 
 
+class ConvBNAct(nn.Sequential):
+    """nn.Sequential(conv, bn[, nonlinear]) of the reference (same child names / state_dict keys); in
+    training mode the BN(+ReLU) runs as one fused statistics pass and one fused apply pass."""
+
+    def forward(self, x):
+        if not (FUSE_BN and self.training and x.is_cuda):
+            return super().forward(x)
+        act = ops.ACT_RELU if hasattr(self, "nonlinear") else ops.ACT_NONE
+        return fused_bn_act(self.conv(x), self.bn, act=act)
+
+
 def conv_bn(in_channels, out_channels, kernel_size, stride, padding, groups, dilation=1):
     if padding is None:
         padding = kernel_size // 2
-    seq = nn.Sequential()
+    seq = ConvBNAct()
     seq.add_module("conv", get_conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation,
                                       groups, False))
     seq.add_module("bn", get_bn(out_channels))
@@ -166,11 +188,19 @@ class ReparamLargeKernelConv(nn.Module):
             return self.lkb_reparam(x)
         if not hasattr(self, "small_conv"):
             return self.lkb_origin(x)
+        return self.forward_act(x, ops.ACT_NONE)
+
+    def forward_act(self, x, act):
+        """act(BN(DW_k(x)) + BN(DW_5(x))): one conv launch + fused BN/activation."""
         big, small = self.lkb_origin.conv, self.small_conv.conv
         if isinstance(big, LargeKernelDW) and small.kernel_size[0] in (3, 5) and small.stride[0] == 1:
             y_big, y_small = ops.dwconv_lk(x, big.weight, small.weight)
-            return self.lkb_origin.bn(y_big) + self.small_conv.bn(y_small)
-        return self.lkb_origin(x) + self.small_conv(x)
+            if FUSE_BN and self.training and x.is_cuda:
+                return fused_bn_act(y_big, self.lkb_origin.bn, y_small, self.small_conv.bn, act=act)
+            out = self.lkb_origin.bn(y_big) + self.small_conv.bn(y_small)
+        else:
+            out = self.lkb_origin(x) + self.small_conv(x)
+        return F.relu(out) if act == ops.ACT_RELU else out
 
     def get_equivalent_kernel_bias(self):
         eq_k, eq_b = fuse_bn(self.lkb_origin.conv, self.lkb_origin.bn)
@@ -209,6 +239,12 @@ class ConvFFN(nn.Module):
         self.gamma, self.test_id = gamma, adpt_test
 
     def forward(self, x):
+        if FUSE_BN and self.training and x.is_cuda:
+            out = fused_bn_act(x, self.preffn_bn)
+            adpt = self.mlp_adapter(out) if self.test_id >= 0 else None
+            h = fused_bn_act(self.pw1.conv(out), self.pw1.bn, act=ops.ACT_GELU)
+            return fused_bn_act(self.pw2.conv(h), self.pw2.bn, mask=_drop_mask(self.drop_path, x), r1=x, r2=adpt,
+                                r2_scale=self.gamma)
         out = self.preffn_bn(x)
         adpt = self.mlp_adapter(out) if self.test_id >= 0 else None
         out = self.pw2(self.nonlinear(self.pw1(out)))
@@ -234,6 +270,12 @@ class RepLKBlock(nn.Module):
         self.gamma, self.test_id = gamma, adpt_test
 
     def forward(self, x):
+        if FUSE_BN and self.training and x.is_cuda and hasattr(self.large_kernel, "small_conv"):
+            out = fused_bn_act(x, self.prelkb_bn)
+            adpt = self.adapter(out) if self.test_id >= 0 else None
+            t = self.large_kernel.forward_act(self.pw1(out), ops.ACT_RELU)
+            return fused_bn_act(self.pw2.conv(t), self.pw2.bn, mask=_drop_mask(self.drop_path, x), r1=x, r2=adpt,
+                                r2_scale=self.gamma)
         out = self.prelkb_bn(x)
         adpt = self.adapter(out) if self.test_id >= 0 else None
         out = self.pw2(self.lk_nonlinear(self.large_kernel(self.pw1(out))))

@@ -343,3 +343,96 @@ def cost_volume_reduce(cost, bins):
     call("ppea_cost_volume_reduce_f32", ptr(cost.contiguous()), ptr(bins.contiguous().float()), ptr(out),
          ptr(conf), ptr(idx), ptr(low), B, D, h, w, stream_ptr())
     return out, conf, idx, low
+
+
+# ---------------------------------------------------------------------------------------------
+# A2 + block glue: y = act(BN_a(z1) [+ BN_b(z2)]) [* mask[n]] [+ r1] [+ s * r2]   (csrc/bn_fused.hip)
+# ---------------------------------------------------------------------------------------------
+import ctypes as _ct
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+def _stats_array(t):
+    """host array of 8 device pointers (NULL for the absent second branch)."""
+    arr = (_ct.c_void_p * 8)()
+    for i, x in enumerate(t):
+        arr[i] = None if x is None else x.data_ptr()
+    return arr
+
+
+def bn_batch_stats(z, eps, momentum, running_mean=None, running_var=None):
+    """(mean, biased var, invstd) of z over (N,H,W); optionally updates running stats in the same launch."""
+    z = z.contiguous()
+    N, C = z.shape[0], z.shape[1]
+    HW = z.numel() // (N * C)
+    dev = z.device
+    partial = torch.empty(C * N * 2, device=dev, dtype=_F32)
+    out = torch.empty(3, C, device=dev, dtype=_F32)
+    call(f"ppea_bn_stats_{_suffix(z)}", ptr(z), ptr(partial), N, C, HW, stream_ptr())
+    call("ppea_bn_finalize_f32", ptr(partial), N, C, HW, float(eps), float(momentum), ptr(out[0]), ptr(out[1]),
+         ptr(out[2]), ptr(running_mean), ptr(running_var), stream_ptr())
+    return out[0], out[1], out[2]
+
+
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z1, g1, b1, mean1, invstd1, z2, g2, b2, mean2, invstd2, mask, r1, r2, r2_scale, act,
+                count, group):
+        z1 = z1.contiguous()
+        N, C = z1.shape[0], z1.shape[1]
+        HW = z1.numel() // (N * C)
+        dt = z1.dtype
+        z2 = None if z2 is None else z2.contiguous().to(dt)
+        r1 = None if r1 is None else r1.contiguous().to(dt)
+        r2 = None if r2 is None else r2.contiguous().to(dt)
+        g1f, b1f = g1.detach().float().contiguous(), b1.detach().float().contiguous()
+        g2f = None if g2 is None else g2.detach().float().contiguous()
+        b2f = None if b2 is None else b2.detach().float().contiguous()
+        maskf = None if mask is None else mask.detach().reshape(-1).float().contiguous()
+        y = torch.empty_like(z1)
+        st = (mean1, invstd1, g1f, b1f, mean2, invstd2, g2f, b2f)
+        call(f"ppea_bn_apply_{_suffix(z1)}", ptr(z1), ptr(z2), _stats_array(st), ptr(maskf), ptr(r1), ptr(r2),
+             float(r2_scale), ptr(y), int(act), N, C, HW, stream_ptr())
+        ctx.save_for_backward(z1, z2, mean1, invstd1, g1f, b1f, mean2, invstd2, g2f, b2f, maskf)
+        ctx.act, ctx.r2_scale, ctx.count, ctx.group = int(act), float(r2_scale), float(count), group
+        ctx.has = (r1 is not None, r2 is not None)
+        ctx.pdt = (g1.dtype, b1.dtype, None if g2 is None else g2.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z1, z2, mean1, invstd1, g1f, b1f, mean2, invstd2, g2f, b2f, maskf = ctx.saved_tensors
+        N, C = z1.shape[0], z1.shape[1]
+        HW = z1.numel() // (N * C)
+        dy = dy.contiguous().to(z1.dtype)
+        dev = z1.device
+        st = _stats_array((mean1, invstd1, g1f, b1f, mean2, invstd2, g2f, b2f))
+        partial = torch.empty(C * N * 3, device=dev, dtype=_F32)
+        sums = torch.empty(3, C, device=dev, dtype=_F32)
+        sfx = _suffix(z1)
+        call(f"ppea_bn_bwd_reduce_{sfx}", ptr(dy), ptr(z1), ptr(z2), st, ptr(maskf), ptr(partial), ctx.act, N, C,
+             HW, stream_ptr())
+        call("ppea_bn_bwd_finalize_f32", ptr(partial), N, C, ptr(sums), stream_ptr())
+        if ctx.group is not None:                      # SyncBN: global sums (count is already global)
+            import torch.distributed as dist
+            dist.all_reduce(sums, group=ctx.group[0])
+        dz1 = torch.empty_like(z1)
+        dz2 = None if z2 is None else torch.empty_like(z2)
+        call(f"ppea_bn_bwd_apply_{sfx}", ptr(dy), ptr(z1), ptr(z2), st, ptr(maskf), ptr(sums), 1.0 / ctx.count,
+             ptr(dz1), ptr(dz2), ctx.act, N, C, HW, stream_ptr())
+        dg1 = sums[1].to(ctx.pdt[0]) if ctx.needs_input_grad[1] else None
+        db1 = sums[0].to(ctx.pdt[1]) if ctx.needs_input_grad[2] else None
+        dg2 = sums[2].to(ctx.pdt[2]) if (z2 is not None and ctx.needs_input_grad[6]) else None
+        db2 = sums[0].to(ctx.pdt[2]) if (z2 is not None and ctx.needs_input_grad[7]) else None
+        dr1 = dy if ctx.has[0] else None
+        dr2 = (dy if ctx.r2_scale == 1.0 else dy * ctx.r2_scale) if ctx.has[1] else None
+        return (dz1, dg1, db1, None, None, dz2, dg2, db2, None, None, None, dr1, dr2, None, None, None, None)
+
+
+def bn_act_apply(z1, g1, b1, mean1, invstd1, z2=None, g2=None, b2=None, mean2=None, invstd2=None, mask=None,
+                 r1=None, r2=None, r2_scale=1.0, act=ACT_NONE, count=None, group=None):
+    if count is None:
+        count = z1.numel() // z1.shape[1]
+    return _BnAct.apply(z1, g1, b1, mean1, invstd1, z2, g2, b2, mean2, invstd2, mask, r1, r2, r2_scale, act, count,
+                        group)

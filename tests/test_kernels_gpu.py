@@ -258,3 +258,58 @@ def test_cost_volume_golden(device, golden):
     assert torch.equal(idx.cpu(), g["argmin"])                      # bit-exact index tensor
     assert rel_err(low.cpu(), g["lowest_cost"]) < FWD_TOL
     assert float(cost[2].abs().max()) == 0.0                        # zeroed pose -> skipped item
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("two,act,res", [(False, 0, False), (False, 1, False), (True, 1, False), (False, 2, False),
+                                         (False, 0, True)])
+@pytest.mark.parametrize("shape", [(3, 8, 12, 40), (2, 5, 7, 9)])
+def test_fused_bn_act(device, dtype, two, act, res, shape):
+    """act(BN_a(z1) [+ BN_b(z2)]) * mask + r1 + s*r2 (training-mode batch statistics), forward, running
+    statistics and all gradients against the oracle composite."""
+    import torch.nn.functional as F
+    from ppeadepth import ops
+    N, C, H, W = shape
+    g = _g(N * 100 + C + act)
+    dt = torch.float32 if dtype == "f32" else torch.bfloat16
+    z1 = (torch.randn(shape, generator=g) * 2 + 0.5).to(dt)
+    z2 = (torch.randn(shape, generator=g) * 0.7 - 0.2).to(dt)
+    g1, b1 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    g2, b2 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    mask = torch.tensor([0.0, 1.4, 1.4][:N])
+    r1 = torch.randn(shape, generator=g).to(dt)
+    r2 = torch.randn(shape, generator=g).to(dt)
+    go = torch.randn(shape, generator=g).to(dt)
+
+    def ref():
+        leaves = [t.float().clone().requires_grad_(True) for t in (z1, z2, g1, b1, g2, b2, r1, r2)]
+        a, bb, w1, c1, w2, c2, q1, q2 = leaves
+        rm, rv = torch.zeros(C), torch.ones(C)
+        u = F.batch_norm(a, rm, rv, w1, c1, True, 0.1, 1e-5)
+        if two:
+            u = u + F.batch_norm(bb, torch.zeros(C), torch.ones(C), w2, c2, True, 0.1, 1e-5)
+        u = F.relu(u) if act == 1 else (F.gelu(u) if act == 2 else u)
+        if res:
+            u = u * mask.view(-1, 1, 1, 1) + q1 + 0.5 * q2
+        (u * go.float()).sum().backward()
+        return u.detach(), leaves, rm, rv
+
+    y_ref, leaves, rm_ref, rv_ref = ref()
+    d = [t.to(device).requires_grad_(True) for t in (z1, z2, g1, b1, g2, b2, r1, r2)]
+    rm, rv = torch.zeros(C, device=device), torch.ones(C, device=device)
+    mean1, _, invstd1 = ops.bn_batch_stats(d[0].detach(), 1e-5, 0.1, rm, rv)
+    kw = {}
+    if two:
+        mean2, _, invstd2 = ops.bn_batch_stats(d[1].detach(), 1e-5, 0.1, None, None)
+        kw.update(z2=d[1], g2=d[4], b2=d[5], mean2=mean2, invstd2=invstd2)
+    if res:
+        kw.update(mask=mask.to(device), r1=d[6], r2=d[7], r2_scale=0.5)
+    y = ops.bn_act_apply(d[0], d[2], d[3], mean1, invstd1, act=act, **kw)
+    (y.float() * go.to(device).float()).sum().backward()
+    tol_f, tol_b = (2e-5, 2e-4) if dtype == "f32" else (1e-2, 3e-2)
+    assert rel_err(y.float().cpu(), y_ref) < tol_f
+    assert rel_err(rm.cpu(), rm_ref) < 1e-5 and rel_err(rv.cpu(), rv_ref) < 1e-4
+    used = [0, 2, 3] + ([1, 4, 5] if two else []) + ([6, 7] if res else [])
+    for i in used:
+        assert rel_err(d[i].grad.float().cpu(), leaves[i].grad) < tol_b, i
