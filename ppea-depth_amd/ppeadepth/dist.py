@@ -116,11 +116,61 @@ class TrainEngine:
         on_gpu = self.params[0].is_cuda
         if fused_adam is None:
             fused_adam = on_gpu
-        self.optimizer = torch.optim.Adam(self.params, lr, fused=True) if fused_adam else \
+        self.optimizer = torch.optim.Adam(self.params, lr, fused=True, capturable=on_gpu) if fused_adam else \
             torch.optim.Adam(self.params, lr, foreach=True)
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, trainer.opt.scheduler_step_size, 0.1)
+        self.graph = None
+        self.static_inputs = None
+        self.static_out = None
+
+    # ---- whole-step hipGraph -------------------------------------------------------------------------
+    # ~10k kernel launches per step make the eager step host-bound (Python + dispatcher ~15 us per
+    # launch); the captured graph replays the same launches (ours and the library ones) from the GPU's
+    # command processor.  Shapes are static; the only per-step host inputs -- the batch and the matching
+    # augmentation draws -- are copied into static buffers before each replay.
+    def capture(self, inputs, warmup=3):
+        from . import rng
+        dev = self.params[0].device
+        self.static_inputs = {k: v.clone() for k, v in inputs.items()}
+        B = self.static_inputs[("color", 0, 0)].shape[0]
+        rng.set_aug_buffer(torch.zeros(B, device=dev))
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                rng.refill_aug_buffer()
+                self._step_body(dict(self.static_inputs))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        rng.refill_aug_buffer()
+        with torch.cuda.graph(self.graph):
+            outputs, losses = self._step_body(dict(self.static_inputs))
+        self.static_out = (outputs, losses)
+
+    def replay(self, inputs=None):
+        from . import rng
+        if inputs is not None:
+            for k, v in inputs.items():
+                if k in self.static_inputs and v.data_ptr() != self.static_inputs[k].data_ptr():
+                    self.static_inputs[k].copy_(v, non_blocking=True)
+        rng.refill_aug_buffer()
+        self.graph.replay()
+        self.trainer.step += 1
+        return self.static_out
+
+    def _step_body(self, inputs):
+        outputs, losses = self.trainer.process_batch(inputs, is_train=True)
+        self.grads.zero()
+        self.grads.rebind()
+        losses["loss"].backward()
+        self.grads.all_reduce_mean()
+        self.optimizer.step()
+        return outputs, losses
 
     def step(self, inputs):
+        if self.graph is not None:
+            return self.replay(inputs)
         outputs, losses = self.trainer.process_batch(inputs, is_train=True)
         self.grads.zero()
         self.grads.rebind()

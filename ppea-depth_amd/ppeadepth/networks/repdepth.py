@@ -181,9 +181,9 @@ class RepDepth(nn.Module):
 
             # matching augmentation (repdepth.py:559-575): one uniform draw per item on the host,
             # applied with two masked selects
-            draws = [rng.uniform01() for _ in range(B)]
-            static = torch.tensor([r < 0.25 for r in draws], device=device)
-            nopose = torch.tensor([0.25 <= r < 0.5 for r in draws], device=device)
+            draws = rng.aug_draws(B, device)
+            static = draws < 0.25
+            nopose = (draws >= 0.25) & (draws < 0.5)
             cur = inputs[("color", 0, 0)]
             lookup_frames = torch.where(static[:, None, None, None, None], cur[:, None].expand_as(lookup_frames),
                                         lookup_frames)

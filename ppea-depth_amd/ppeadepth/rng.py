@@ -42,3 +42,26 @@ def randn_like_cpu_order(shape, device) -> torch.Tensor:
 
 def uniform01() -> float:
     return random.random()
+
+
+_AUG_BUFFER = None      # static device tensor [B] the captured step graph reads its draws from
+
+
+def set_aug_buffer(t):
+    global _AUG_BUFFER
+    _AUG_BUFFER = t
+
+
+def refill_aug_buffer():
+    """Host side of the matching augmentation: B uniform draws (python `random`, like the reference) copied
+    into the static buffer before the step graph is replayed."""
+    if _AUG_BUFFER is not None:
+        _AUG_BUFFER.copy_(torch.tensor([random.random() for _ in range(_AUG_BUFFER.shape[0])]),
+                          non_blocking=True)
+
+
+def aug_draws(batch: int, device) -> torch.Tensor:
+    """One uniform draw per batch item (networks/repdepth.py:561-575) as a device tensor."""
+    if _AUG_BUFFER is not None:
+        return _AUG_BUFFER
+    return torch.tensor([random.random() for _ in range(batch)], device=device)
