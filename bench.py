@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--rep_size", default="b", choices=["b", "l"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="no hipGraph: launch every kernel from Python")
     args = ap.parse_args()
 
     from ppeadepth import dist as pdist
@@ -113,13 +114,22 @@ def main():
     for _ in range(args.warmup):
         engine.step(dict(inputs))
     barrier()
-    ops.PROFILE_DWCONV = []                       # (K, start_event, end_event) per k=31 launch
+    # roofline probe: HIP events around every k=31 launch of ONE eager step (events cannot be recorded
+    # inside a captured graph); the same kernels with the same arguments are what the graph replays.
+    ops.PROFILE_DWCONV = []                       # (kind, start_event, end_event) per k=31 launch
+    engine.step(dict(inputs))
+    barrier()
+    events, ops.PROFILE_DWCONV = ops.PROFILE_DWCONV, None
+    if not args.eager:
+        engine.capture(inputs, warmup=1)
+        for _ in range(2):
+            engine.step(inputs)
+        barrier()
     t0 = time.time()
     for _ in range(args.steps):
-        _, losses = engine.step(dict(inputs))
+        _, losses = engine.step(dict(inputs) if args.eager else inputs)
     barrier()
     dt = time.time() - t0
-    events, ops.PROFILE_DWCONV = ops.PROFILE_DWCONV, None
     loss_val = float(losses["loss"])
 
     t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -158,7 +168,8 @@ def main():
             "config": {"workload": f"RepLKNet-31{args.rep_size.upper()} Stage-1 640x192, {B} frame triplets/GPU, "
                                    "process_batch + backward + grad all-reduce + Adam",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
-                       "use_checkpoint": "BN-stat replay, no recompute (288 GB HBM)"},
+                       "use_checkpoint": "BN-stat replay, no recompute (288 GB HBM)",
+                       "launch": "eager" if args.eager else "whole step captured in one hipGraph"},
             "final_loss": round(loss_val, 5),
             "roofline": roof,
         }
