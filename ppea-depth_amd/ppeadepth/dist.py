@@ -122,6 +122,10 @@ class TrainEngine:
         self.graph = None
         self.static_inputs = None
         self.static_out = None
+        # every step -- eager or captured -- runs on ONE non-default stream: autograd's AccumulateGrad
+        # nodes remember the stream they were created on, and a captured backward must not touch the
+        # legacy default stream.
+        self.stream = torch.cuda.Stream(self.params[0].device) if on_gpu else None
 
     # ---- whole-step hipGraph -------------------------------------------------------------------------
     # ~10k kernel launches per step make the eager step host-bound (Python + dispatcher ~15 us per
@@ -134,17 +138,18 @@ class TrainEngine:
         self.static_inputs = {k: v.clone() for k, v in inputs.items()}
         B = self.static_inputs[("color", 0, 0)].shape[0]
         rng.set_aug_buffer(torch.zeros(B, device=dev))
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        import gc
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
             for _ in range(warmup):
                 rng.refill_aug_buffer()
                 self._step_body(dict(self.static_inputs))
-        torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        gc.collect()                        # drop autograd graphs of earlier steps before capturing
         self.graph = torch.cuda.CUDAGraph()
         rng.refill_aug_buffer()
-        with torch.cuda.graph(self.graph):
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.graph, stream=self.stream):
             outputs, losses = self._step_body(dict(self.static_inputs))
         self.static_out = (outputs, losses)
 
@@ -154,8 +159,9 @@ class TrainEngine:
             for k, v in inputs.items():
                 if k in self.static_inputs and v.data_ptr() != self.static_inputs[k].data_ptr():
                     self.static_inputs[k].copy_(v, non_blocking=True)
-        rng.refill_aug_buffer()
-        self.graph.replay()
+        with torch.cuda.stream(self.stream):
+            rng.refill_aug_buffer()
+            self.graph.replay()
         self.trainer.step += 1
         return self.static_out
 
@@ -171,11 +177,11 @@ class TrainEngine:
     def step(self, inputs):
         if self.graph is not None:
             return self.replay(inputs)
-        outputs, losses = self.trainer.process_batch(inputs, is_train=True)
-        self.grads.zero()
-        self.grads.rebind()
-        losses["loss"].backward()
-        self.grads.all_reduce_mean()
-        self.optimizer.step()
+        if self.stream is None:
+            outputs, losses = self._step_body(inputs)
+        else:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                outputs, losses = self._step_body(inputs)
         self.trainer.step += 1
         return outputs, losses
