@@ -114,6 +114,15 @@ int ppea_bn_bwd_apply_bf16(const void* dy, const void* z1, const void* z2, const
                            int act, int N, int C, int HW, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * A12 glue  nn.ReflectionPad2d(1) of the decoder's Conv3x3 (layers.py:119-135).  in [planes,H,W] ->
+ *     out [planes,H+2,W+2]; backward is a gather (no atomics): din [planes,H,W] from dout.  H, W >= 3.
+ * ---------------------------------------------------------------------------------------- */
+int ppea_reflect_pad1_fwd_f32(const void* in, void* out, long planes, int H, int W, void* stream);
+int ppea_reflect_pad1_fwd_bf16(const void* in, void* out, long planes, int H, int W, void* stream);
+int ppea_reflect_pad1_bwd_f32(const void* dout, void* din, long planes, int H, int W, void* stream);
+int ppea_reflect_pad1_bwd_bf16(const void* dout, void* din, long planes, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * A18+A19  BackprojectDepth -> Project3D fused (layers.py:138-199; trainer.py:904-907).
  *     depth [B,1,H,W]; inv_K [B,4,4] (only [:3,:3] read); P [B,3,4] = (K @ T)[:, :3, :];
  *     grid [B,H,W,2] normalised to [-1,1] (x then y); eps added to z (1e-7).

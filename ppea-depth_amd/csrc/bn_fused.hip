@@ -289,6 +289,147 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply(const T* __restrict__ dy, co
     }
 }
 
+// ---- small planes (HW <= 4096, HW % 8 == 0): one WAVE per plane, no LDS, no barriers -----------------
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_stats_wave(const T* __restrict__ z, float* __restrict__ partial, int N,
+                                                     int C, int HW, long planes) {
+    const long plane = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & 63;
+    const int n = (int)(plane / C), c = (int)(plane - (long)n * C);
+    const T* p = z + plane * HW;
+    float s = 0.f;
+    for (int i = lane * V; i < HW; i += WAVE * V) {
+        float x[V];
+        ld8<T>(p + i, x);
+#pragma unroll
+        for (int k = 0; k < V; ++k) s += x[k];
+    }
+    const float mean = wave_sum(s) / (float)HW;
+    float m2 = 0.f;
+    for (int i = lane * V; i < HW; i += WAVE * V) {
+        float x[V];
+        ld8<T>(p + i, x);
+#pragma unroll
+        for (int k = 0; k < V; ++k) m2 += (x[k] - mean) * (x[k] - mean);
+    }
+    m2 = wave_sum(m2);
+    if (lane == 0) {
+        partial[((long)c * N + n) * 2] = mean;
+        partial[((long)c * N + n) * 2 + 1] = m2;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_wave(const T* __restrict__ dy, const T* __restrict__ z1,
+                                                          const T* __restrict__ z2, Branch b1, Branch b2,
+                                                          const float* __restrict__ mask,
+                                                          float* __restrict__ partial, int act, int N, int C, int HW,
+                                                          long planes) {
+    const long plane = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (plane >= planes) return;
+    const int lane = threadIdx.x & 63;
+    const int n = (int)(plane / C), c = (int)(plane - (long)n * C);
+    const float is1 = b1.invstd[c], mu1 = b1.mean[c];
+    const float a1 = b1.gamma[c] * is1, o1 = b1.beta[c] - mu1 * a1;
+    float is2 = 0.f, mu2 = 0.f, a2 = 0.f, o2 = 0.f;
+    if (z2 != nullptr) { is2 = b2.invstd[c]; mu2 = b2.mean[c]; a2 = b2.gamma[c] * is2; o2 = b2.beta[c] - mu2 * a2; }
+    const float m = (mask != nullptr) ? mask[n] : 1.f;
+    const long base = plane * HW;
+    float sg = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int i = lane * V; i < HW; i += WAVE * V) {
+        float x1[V], x2[V], d[V];
+        ld8<T>(z1 + base + i, x1);
+        if (z2 != nullptr) ld8<T>(z2 + base + i, x2);
+        ld8<T>(dy + base + i, d);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float u = a1 * x1[k] + o1;
+            float xx2 = 0.f;
+            if (z2 != nullptr) { xx2 = x2[k]; u += a2 * xx2 + o2; }
+            const float g = d[k] * m * act_bwd(u, act);
+            sg += g;
+            s1 += g * (x1[k] - mu1) * is1;
+            s2 += g * (xx2 - mu2) * is2;
+        }
+    }
+    sg = wave_sum(sg); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+        float* p = partial + ((long)c * N + n) * 3;
+        p[0] = sg; p[1] = s1; p[2] = s2;
+    }
+}
+
+// ---- flat element-wise passes (HW % 8 == 0): 8 elements per thread, channel looked up per thread -------
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_apply_flat(const T* __restrict__ z1, const T* __restrict__ z2, Branch b1,
+                                                     Branch b2, const float* __restrict__ mask,
+                                                     const T* __restrict__ r1, const T* __restrict__ r2,
+                                                     float r2_scale, T* __restrict__ y, int act, int C, int HW,
+                                                     long total8) {
+    const long t = (long)blockIdx.x * TPB + threadIdx.x;
+    if (t >= total8) return;
+    const long i = t * V;
+    const long plane = i / HW;
+    const int n = (int)(plane / C), c = (int)(plane - (long)n * C);
+    const float a1 = b1.gamma[c] * b1.invstd[c], o1 = b1.beta[c] - b1.mean[c] * a1;
+    float a2 = 0.f, o2 = 0.f;
+    if (z2 != nullptr) { a2 = b2.gamma[c] * b2.invstd[c]; o2 = b2.beta[c] - b2.mean[c] * a2; }
+    const float m = (mask != nullptr) ? mask[n] : 1.f;
+    float x1[V], x2[V], q1[V], q2[V], o[V];
+    ld8<T>(z1 + i, x1);
+    if (z2 != nullptr) ld8<T>(z2 + i, x2);
+    if (r1 != nullptr) ld8<T>(r1 + i, q1);
+    if (r2 != nullptr) ld8<T>(r2 + i, q2);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        float u = a1 * x1[k] + o1;
+        if (z2 != nullptr) u += a2 * x2[k] + o2;
+        float v = act_fwd(u, act) * m;
+        if (r1 != nullptr) v += q1[k];
+        if (r2 != nullptr) v += r2_scale * q2[k];
+        o[k] = v;
+    }
+    st8<T>(y + i, o);
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_flat(const T* __restrict__ dy, const T* __restrict__ z1,
+                                                         const T* __restrict__ z2, Branch b1, Branch b2,
+                                                         const float* __restrict__ mask,
+                                                         const float* __restrict__ sums, float inv_count,
+                                                         T* __restrict__ dz1, T* __restrict__ dz2, int act, int C,
+                                                         int HW, long total8) {
+    const long t = (long)blockIdx.x * TPB + threadIdx.x;
+    if (t >= total8) return;
+    const long i = t * V;
+    const long plane = i / HW;
+    const int n = (int)(plane / C), c = (int)(plane - (long)n * C);
+    const float is1 = b1.invstd[c], mu1 = b1.mean[c];
+    const float a1 = b1.gamma[c] * is1, o1 = b1.beta[c] - mu1 * a1;
+    float is2 = 0.f, mu2 = 0.f, a2 = 0.f, o2 = 0.f;
+    if (z2 != nullptr) { is2 = b2.invstd[c]; mu2 = b2.mean[c]; a2 = b2.gamma[c] * is2; o2 = b2.beta[c] - mu2 * a2; }
+    const float m = (mask != nullptr) ? mask[n] : 1.f;
+    const float mg = sums[c] * inv_count, m1 = sums[C + c] * inv_count, m2 = sums[2 * C + c] * inv_count;
+    float x1[V], x2[V], d[V], o1v[V], o2v[V];
+    ld8<T>(z1 + i, x1);
+    if (z2 != nullptr) ld8<T>(z2 + i, x2);
+    ld8<T>(dy + i, d);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        float u = a1 * x1[k] + o1;
+        float xx2 = 0.f;
+        if (z2 != nullptr) { xx2 = x2[k]; u += a2 * xx2 + o2; }
+        const float g = d[k] * m * act_bwd(u, act);
+        o1v[k] = a1 * (g - mg - (x1[k] - mu1) * is1 * m1);
+        o2v[k] = a2 * (g - mg - (xx2 - mu2) * is2 * m2);
+    }
+    st8<T>(dz1 + i, o1v);
+    if (z2 != nullptr) st8<T>(dz2 + i, o2v);
+}
+
+constexpr int SMALL_PLANE = 4096;
+
 inline int plane_chunks(long planes, int HW) {
     // enough blocks to fill the chip (>= ~2048) without making them tiny
     int chunks = 1;
@@ -299,8 +440,13 @@ inline int plane_chunks(long planes, int HW) {
 template <typename T>
 int stats_impl(const void* z, float* partial, int N, int C, int HW, void* stream) {
     if (N <= 0 || C <= 0 || HW <= 0) return PPEA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bn_stats<T>, dim3((unsigned)((long)N * C)), dim3(TPB), 0, (hipStream_t)stream, (const T*)z,
-                       partial, N, C, HW);
+    const long planes = (long)N * C;
+    if (HW % V == 0 && HW <= SMALL_PLANE)
+        hipLaunchKernelGGL(bn_stats_wave<T>, dim3((unsigned)((planes + 3) / 4)), dim3(TPB), 0, (hipStream_t)stream,
+                           (const T*)z, partial, N, C, HW, planes);
+    else
+        hipLaunchKernelGGL(bn_stats<T>, dim3((unsigned)planes), dim3(TPB), 0, (hipStream_t)stream, (const T*)z,
+                           partial, N, C, HW);
     return launch_status();
 }
 
@@ -309,6 +455,13 @@ int apply_impl(const void* z1, const void* z2, const float* const* st, const flo
                const void* r2, float r2_scale, void* y, int act, int N, int C, int HW, void* stream) {
     if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return PPEA_ERR_UNSUPPORTED;
     const Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
+    if (HW % V == 0) {
+        const long total8 = (long)N * C * HW / V;
+        hipLaunchKernelGGL(bn_apply_flat<T>, dim3((unsigned)((total8 + TPB - 1) / TPB)), dim3(TPB), 0,
+                           (hipStream_t)stream, (const T*)z1, (const T*)z2, b1, b2, mask, (const T*)r1,
+                           (const T*)r2, r2_scale, (T*)y, act, C, HW, total8);
+        return launch_status();
+    }
     const int chunks = plane_chunks((long)N * C, HW);
     hipLaunchKernelGGL(bn_apply<T>, dim3((unsigned)((long)N * C * chunks)), dim3(TPB), 0, (hipStream_t)stream,
                        (const T*)z1, (const T*)z2, b1, b2, mask, (const T*)r1, (const T*)r2, r2_scale, (T*)y, act, C,
@@ -321,8 +474,14 @@ int bwd_reduce_impl(const void* dy, const void* z1, const void* z2, const float*
                     float* partial, int act, int N, int C, int HW, void* stream) {
     if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return PPEA_ERR_UNSUPPORTED;
     const Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
-    hipLaunchKernelGGL(bn_bwd_reduce<T>, dim3((unsigned)((long)N * C)), dim3(TPB), 0, (hipStream_t)stream,
-                       (const T*)dy, (const T*)z1, (const T*)z2, b1, b2, mask, partial, act, N, C, HW);
+    const long planes = (long)N * C;
+    if (HW % V == 0 && HW <= SMALL_PLANE)
+        hipLaunchKernelGGL(bn_bwd_reduce_wave<T>, dim3((unsigned)((planes + 3) / 4)), dim3(TPB), 0,
+                           (hipStream_t)stream, (const T*)dy, (const T*)z1, (const T*)z2, b1, b2, mask, partial, act,
+                           N, C, HW, planes);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce<T>, dim3((unsigned)planes), dim3(TPB), 0, (hipStream_t)stream,
+                           (const T*)dy, (const T*)z1, (const T*)z2, b1, b2, mask, partial, act, N, C, HW);
     return launch_status();
 }
 
@@ -332,6 +491,13 @@ int bwd_apply_impl(const void* dy, const void* z1, const void* z2, const float* 
                    void* stream) {
     if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return PPEA_ERR_UNSUPPORTED;
     const Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
+    if (HW % V == 0) {
+        const long total8 = (long)N * C * HW / V;
+        hipLaunchKernelGGL(bn_bwd_apply_flat<T>, dim3((unsigned)((total8 + TPB - 1) / TPB)), dim3(TPB), 0,
+                           (hipStream_t)stream, (const T*)dy, (const T*)z1, (const T*)z2, b1, b2, mask, sums,
+                           inv_count, (T*)dz1, (T*)dz2, act, C, HW, total8);
+        return launch_status();
+    }
     const int chunks = plane_chunks((long)N * C, HW);
     hipLaunchKernelGGL(bn_bwd_apply<T>, dim3((unsigned)((long)N * C * chunks)), dim3(TPB), 0, (hipStream_t)stream,
                        (const T*)dy, (const T*)z1, (const T*)z2, b1, b2, mask, sums, inv_count, (T*)dz1, (T*)dz2, act,

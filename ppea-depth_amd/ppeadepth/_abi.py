@@ -38,6 +38,10 @@ SIGNATURES = {
     "ppea_bn_bwd_finalize_f32": [_vp, _i, _i, _vp, _vp],
     "ppea_bn_bwd_apply_f32": [_vp] * 6 + [_f, _vp, _vp] + [_i] * 4 + [_vp],
     "ppea_bn_bwd_apply_bf16": [_vp] * 6 + [_f, _vp, _vp] + [_i] * 4 + [_vp],
+    "ppea_reflect_pad1_fwd_f32": [_vp, _vp, _l, _i, _i, _vp],
+    "ppea_reflect_pad1_fwd_bf16": [_vp, _vp, _l, _i, _i, _vp],
+    "ppea_reflect_pad1_bwd_f32": [_vp, _vp, _l, _i, _i, _vp],
+    "ppea_reflect_pad1_bwd_bf16": [_vp, _vp, _l, _i, _i, _vp],
     "ppea_backproject_project_fwd_f32": [_vp] * 4 + [_i] * 3 + [_f, _vp],
     "ppea_backproject_project_bwd_f32": [_vp] * 6 + [_i] * 3 + [_f, _vp],
     "ppea_grid_sample_fwd_f32": [_vp] * 3 + [_i] * 7 + [_vp],

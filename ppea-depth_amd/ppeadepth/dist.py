@@ -83,6 +83,23 @@ class FlatGrads:
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
                 p.grad = self.flat[off:off + p.numel()].view_as(p)
 
+    def gather_and_all_reduce(self):
+        """Pack the freshly produced gradients into the flat buffer with ONE multi-tensor copy, all-reduce
+        the buffer in a few large chunks, and hand the views back to the optimizer."""
+        views, grads = [], []
+        for p, off in zip(self.params, self.offsets):
+            v = self.flat[off:off + p.numel()].view_as(p)
+            views.append(v)
+            if p.grad is None:
+                v.zero_()
+            else:
+                grads.append((v, p.grad))
+        if grads:
+            torch._foreach_copy_([v for v, _ in grads], [g for _, g in grads])
+        for p, v in zip(self.params, views):
+            p.grad = v
+        self.all_reduce_mean()
+
     def all_reduce_mean(self):
         """Mean over ranks (DDP semantics).  Call after backward; returns when the reduced gradients
         are visible to the current stream."""
@@ -167,10 +184,17 @@ class TrainEngine:
 
     def _step_body(self, inputs):
         outputs, losses = self.trainer.process_batch(inputs, is_train=True)
-        self.grads.zero()
-        self.grads.rebind()
-        losses["loss"].backward()
-        self.grads.all_reduce_mean()
+        if world_size() == 1:
+            # one rank: gradients stay where autograd puts them (no 1 306 accumulate-into-view kernels);
+            # the fused multi-tensor Adam reads the list directly
+            for p in self.params:
+                p.grad = None
+            losses["loss"].backward()
+        else:
+            for p in self.params:
+                p.grad = None
+            losses["loss"].backward()
+            self.grads.gather_and_all_reduce()
         self.optimizer.step()
         return outputs, losses
 

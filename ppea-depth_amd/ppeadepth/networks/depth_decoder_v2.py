@@ -21,10 +21,8 @@ class Adapter(nn.Module):
         nn.init.constant_(self.D_fc2.bias, 0)
 
     def forward(self, x):
-        B, C, H, W = x.shape
-        t = x.flatten(2).permute(0, 2, 1)
-        t = self.D_fc2(self.act(self.D_fc1(t)))
-        return t.permute(0, 2, 1).reshape(B, -1, H, W)
+        h = self.act(F.conv2d(x, self.D_fc1.weight[:, :, None, None], self.D_fc1.bias))
+        return F.conv2d(h, self.D_fc2.weight[:, :, None, None], self.D_fc2.bias)
 
 
 class DepthDecoderV2(nn.Module):

@@ -436,3 +436,31 @@ def bn_act_apply(z1, g1, b1, mean1, invstd1, z2=None, g2=None, b2=None, mean2=No
         count = z1.numel() // z1.shape[1]
     return _BnAct.apply(z1, g1, b1, mean1, invstd1, z2, g2, b2, mean2, invstd2, mask, r1, r2, r2_scale, act, count,
                         group)
+
+
+# ---------------------------------------------------------------------------------------------
+# A12 glue: ReflectionPad2d(1)                                            layers.py:119-135
+# ---------------------------------------------------------------------------------------------
+class _ReflectPad1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty(B, C, H + 2, W + 2, device=x.device, dtype=x.dtype)
+        call(f"ppea_reflect_pad1_fwd_{_suffix(x)}", ptr(x), ptr(out), B * C, H, W, stream_ptr())
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C, H, W = ctx.shape
+        dout = dout.contiguous()
+        din = torch.empty(B, C, H, W, device=dout.device, dtype=dout.dtype)
+        call(f"ppea_reflect_pad1_bwd_{_suffix(dout)}", ptr(dout), ptr(din), B * C, H, W, stream_ptr())
+        return din
+
+
+def reflect_pad1(x):
+    if x.shape[-1] < 3 or x.shape[-2] < 3 or x.dtype not in (_F32, _BF16) or not x.is_cuda:
+        return torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect")
+    return _ReflectPad1.apply(x)

@@ -264,7 +264,7 @@ def test_cost_volume_golden(device, golden):
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("two,act,res", [(False, 0, False), (False, 1, False), (True, 1, False), (False, 2, False),
                                          (False, 0, True)])
-@pytest.mark.parametrize("shape", [(3, 8, 12, 40), (2, 5, 7, 9)])
+@pytest.mark.parametrize("shape", [(3, 8, 12, 40), (2, 5, 7, 9), (2, 4, 48, 160)])
 def test_fused_bn_act(device, dtype, two, act, res, shape):
     """act(BN_a(z1) [+ BN_b(z2)]) * mask + r1 + s*r2 (training-mode batch statistics), forward, running
     statistics and all gradients against the oracle composite."""
@@ -313,3 +313,19 @@ def test_fused_bn_act(device, dtype, two, act, res, shape):
     used = [0, 2, 3] + ([1, 4, 5] if two else []) + ([6, 7] if res else [])
     for i in used:
         assert rel_err(d[i].grad.float().cpu(), leaves[i].grad) < tol_b, i
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 3, 6, 20), (1, 2, 3, 3), (2, 4, 24, 80), (1, 1, 3, 9)])
+def test_reflect_pad1(device, dtype, shape):
+    import torch.nn.functional as F
+    from ppeadepth import ops
+    x = torch.randn(shape, generator=_g(shape[2])).to(dtype)
+    go = torch.randn(shape[0], shape[1], shape[2] + 2, shape[3] + 2, generator=_g(3)).to(dtype)
+    xr = x.float().clone().requires_grad_(True)
+    (F.pad(xr, (1, 1, 1, 1), mode="reflect") * go.float()).sum().backward()
+    xd = x.to(device).requires_grad_(True)
+    y = ops.reflect_pad1(xd)
+    assert torch.equal(y.detach().cpu(), F.pad(x, (1, 1, 1, 1), mode="reflect"))
+    (y.float() * go.to(device).float()).sum().backward()
+    assert rel_err(xd.grad.float().cpu(), xr.grad) < (1e-6 if dtype == torch.float32 else 1e-2)
