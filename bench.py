@@ -100,7 +100,7 @@ def main():
     pdist.broadcast_module(model)
     amp = torch.bfloat16 if args.dtype == "bf16" else None
     trainer = Trainer(opt, model, device, amp_dtype=amp)
-    engine = pdist.TrainEngine(trainer)
+    engine = pdist.TrainEngine(trainer, bf16_params=(args.dtype == "bf16"))
     rng.set_mode("device")
     inputs = {k: v.to(device) for k, v in synth.make_inputs(B, H, W, seed=1234 + rank, smooth=True).items()}
     random.seed(1000 + rank)

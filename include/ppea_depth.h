@@ -68,6 +68,13 @@ int ppea_dwconv_lk_bwd_data_bf16p(const uint16_t* dy_big, const uint16_t* dy_sma
                                   const void* packed_big_flip, const void* packed_small_flip,
                                   uint16_t* dx, int N, int C, int H, int W, int K, int KS, void* stream);
 
+/* Depthwise 3x3, stride 1 or 2, pad 1, no bias (stem[1], stem[3], transitions[.][1];
+ * replknet_adapter.py:414-416, 451-453).  w [C,1,3,3] fp32.  bwd_data: H, W are the forward INPUT sizes. */
+int ppea_dwconv3x3_fwd_f32(const void* x, const float* w, void* y, int N, int C, int H, int W, int stride, void* stream);
+int ppea_dwconv3x3_fwd_bf16(const void* x, const float* w, void* y, int N, int C, int H, int W, int stride, void* stream);
+int ppea_dwconv3x3_bwd_data_f32(const void* dy, const float* w, void* dx, int N, int C, int H, int W, int stride, void* stream);
+int ppea_dwconv3x3_bwd_data_bf16(const void* dy, const float* w, void* dx, int N, int C, int H, int W, int stride, void* stream);
+
 /* wgrad (only needed with --fullft_reb, repdepth.py:47, and by the plug-in's weight.grad):
  * dw[c,0,u,v] = sum_{n,i,j} dy[n,c,i,j] * x[n,c,i+u-K/2,j+v-K/2].  dw is overwritten. */
 int ppea_dwconv_lk_bwd_filter_f32(const float* x, const float* dy, float* dw,

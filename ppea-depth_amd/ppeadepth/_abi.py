@@ -24,6 +24,10 @@ SIGNATURES = {
     "ppea_dwconv_lk_bwd_data_f32": [_vp] * 5 + [_i] * 6 + [_vp],
     "ppea_dwconv_lk_bwd_data_bf16": [_vp] * 5 + [_i] * 6 + [_vp],
     "ppea_dwconv_lk_bwd_filter_f32": [_vp] * 3 + [_i] * 5 + [_vp],
+    "ppea_dwconv3x3_fwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ppea_dwconv3x3_fwd_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ppea_dwconv3x3_bwd_data_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ppea_dwconv3x3_bwd_data_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ppea_dwconv_lk_packed_bytes": [_i, _i],
     "ppea_dwconv_lk_pack_bf16": [_vp, _vp, _i, _i, _i, _vp],
     "ppea_dwconv_lk_fwd_bf16p": [_vp] * 5 + [_i] * 6 + [_vp],

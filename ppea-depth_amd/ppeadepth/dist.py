@@ -124,17 +124,30 @@ class FlatGrads:
 class TrainEngine:
     """process_batch -> backward -> gradient exchange -> Adam step (trainer.py:345-351)."""
 
-    def __init__(self, trainer, lr=None, n_chunks=4, fused_adam=None):
+    def __init__(self, trainer, lr=None, n_chunks=4, fused_adam=None, bf16_params=False):
         self.trainer = trainer
         model = trainer._module()
+        self.masters = None
+        if bf16_params:
+            self._to_bf16_params(model)
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.grads = FlatGrads(self.params, n_chunks=n_chunks)
         lr = trainer.opt.learning_rate if lr is None else lr
         on_gpu = self.params[0].is_cuda
         if fused_adam is None:
             fused_adam = on_gpu
-        self.optimizer = torch.optim.Adam(self.params, lr, fused=True, capturable=on_gpu) if fused_adam else \
-            torch.optim.Adam(self.params, lr, foreach=True)
+        opt_params = self.params
+        if self.masters is not None:
+            # fp32 master copy per bf16 parameter (others are their own master); Adam runs on the masters
+            opt_params = [self.masters.get(id(p), p) for p in self.params]
+            self._lo = [p for p in self.params if id(p) in self.masters]
+            self._hi = [self.masters[id(p)] for p in self._lo]
+            self._hi_grads = [torch.zeros_like(m) for m in self._hi]
+            for m, g in zip(self._hi, self._hi_grads):
+                m.grad = g
+        self.opt_params = opt_params
+        self.optimizer = torch.optim.Adam(opt_params, lr, fused=True, capturable=on_gpu) if fused_adam else \
+            torch.optim.Adam(opt_params, lr, foreach=True)
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, trainer.opt.scheduler_step_size, 0.1)
         self.graph = None
         self.static_inputs = None
@@ -143,6 +156,40 @@ class TrainEngine:
         # nodes remember the stream they were created on, and a captured backward must not touch the
         # legacy default stream.
         self.stream = torch.cuda.Stream(self.params[0].device) if on_gpu else None
+
+    # ---- bf16 parameters with fp32 masters -----------------------------------------------------------
+    # Under autocast every dense conv / linear casts its fp32 weight to bf16 on each use (~730 cast kernels
+    # per step) and its bf16 weight gradient back to fp32 (~590).  Dense-conv / linear / deconv weights
+    # and biases are therefore stored in bf16 (frozen ones once and for all); trainable ones keep an
+    # fp32 master that Adam updates, and two multi-tensor copies per step move gradients up and weights
+    # down.  BN affine parameters and depthwise filters stay fp32 (the HIP kernels read them as such).
+    def _to_bf16_params(self, model):
+        import torch.nn as nn
+        self.masters = {}
+        for m in model.modules():
+            dense = isinstance(m, (nn.Linear, nn.ConvTranspose2d)) or (isinstance(m, nn.Conv2d) and m.groups == 1)
+            if not dense:
+                continue
+            for p in (m.weight, m.bias):
+                if p is None or p.dtype != torch.float32:
+                    continue
+                if p.requires_grad:
+                    master = p.detach().clone()
+                    master.requires_grad_(True)
+                    self.masters[id(p)] = master
+                p.data = p.data.to(torch.bfloat16)
+
+    def export_state_dict(self):
+        """state_dict with the fp32 masters substituted for the bf16 working copies (checkpoint format)."""
+        model = self.trainer._module()
+        sd = model.state_dict()
+        if self.masters is not None:
+            for name, p in model.named_parameters():
+                if id(p) in self.masters:
+                    sd[name] = self.masters[id(p)].detach().clone()
+                elif p.dtype == torch.bfloat16:
+                    sd[name] = p.detach().float()
+        return sd
 
     # ---- whole-step hipGraph -------------------------------------------------------------------------
     # ~10k kernel launches per step make the eager step host-bound (Python + dispatcher ~15 us per
@@ -195,7 +242,17 @@ class TrainEngine:
                 p.grad = None
             losses["loss"].backward()
             self.grads.gather_and_all_reduce()
-        self.optimizer.step()
+        if self.masters is not None:
+            if self._lo:
+                torch._foreach_copy_(self._hi_grads, [p.grad for p in self._lo])     # bf16 grads -> fp32
+            for p in self.params:
+                if id(p) not in self.masters:
+                    pass                                                             # own master: p.grad used as is
+            self.optimizer.step()
+            if self._lo:
+                torch._foreach_copy_(self._lo, self._hi)                             # masters -> bf16 weights
+        else:
+            self.optimizer.step()
         return outputs, losses
 
     def step(self, inputs):

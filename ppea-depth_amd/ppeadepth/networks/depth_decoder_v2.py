@@ -21,8 +21,8 @@ class Adapter(nn.Module):
         nn.init.constant_(self.D_fc2.bias, 0)
 
     def forward(self, x):
-        h = self.act(F.conv2d(x, self.D_fc1.weight[:, :, None, None], self.D_fc1.bias))
-        return F.conv2d(h, self.D_fc2.weight[:, :, None, None], self.D_fc2.bias)
+        from .replknet_adapter import channel_linear
+        return channel_linear(self.act(channel_linear(x, self.D_fc1)), self.D_fc2)
 
 
 class DepthDecoderV2(nn.Module):

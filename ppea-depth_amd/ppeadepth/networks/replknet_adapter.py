@@ -74,8 +74,20 @@ class LargeKernelDW(nn.Conv2d):
         return y
 
 
+class SmallDW(nn.Conv2d):
+    """Depthwise 3x3, stride 1/2, pad 1 (stem / transitions) on the HIP stencil kernel when frozen."""
+
+    def forward(self, x):
+        if x.is_cuda and not self.weight.requires_grad and self.bias is None:
+            return ops.dwconv3x3(x, self.weight, self.stride[0])
+        return super().forward(x)
+
+
 def get_conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias):
     k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+    if (in_channels == out_channels == groups and k == 3 and stride in (1, 2) and padding == 1 and dilation == 1
+            and groups > 1):
+        return SmallDW(in_channels, out_channels, 3, stride, 1, 1, groups, bias)
     if (in_channels == out_channels == groups and k > 5 and stride == 1 and padding == k // 2
             and dilation == 1):
         return LargeKernelDW(in_channels, k, bias=bias)
@@ -116,6 +128,15 @@ def fuse_bn(conv, bn):
     return conv.weight * t, bn.bias - bn.running_mean * bn.weight / std
 
 
+def channel_linear(x, lin):
+    """nn.Linear `lin` applied over the channel axis of x [B,C,H,W] -> [B,C_out,H,W]."""
+    B, C, H, W = x.shape
+    y = torch.matmul(lin.weight, x.flatten(2))
+    if lin.bias is not None:
+        y = y + lin.bias[:, None]
+    return y.view(B, -1, H, W)
+
+
 class Adapter(nn.Module):
     """rka.py:20-47: token-wise MLP adapter Linear -> GELU -> Linear on [B,HW,C]."""
 
@@ -128,9 +149,9 @@ class Adapter(nn.Module):
         self.D_fc2 = nn.Linear(hidden, D_features)
 
     def forward(self, x):
-        # Linear over the channel axis of [B,HW,C] == 1x1 conv on NCHW: no permute / reshape copies
-        h = self.act(F.conv2d(x, self.D_fc1.weight[:, :, None, None], self.D_fc1.bias))
-        return F.conv2d(h, self.D_fc2.weight[:, :, None, None], self.D_fc2.bias)
+        # Linear over the channel axis of [B,HW,C] == W @ x[B,C,HW] on NCHW: no permute / reshape copies,
+        # one strided-batched GEMM per projection (weight broadcast over the batch)
+        return channel_linear(self.act(channel_linear(x, self.D_fc1)), self.D_fc2)
 
 
 class B_Adapter(nn.Module):
@@ -153,9 +174,8 @@ class B_Adapter(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
-        if self.test_id == 4:      # Conv3x3 -> GELU -> Linear(C/4 -> C) as a 1x1 conv (no permute copies)
-            h = self.act(self.D_fc1(x))
-            return F.conv2d(h, self.D_fc2.weight[:, :, None, None], self.D_fc2.bias)
+        if self.test_id == 4:      # Conv3x3 -> GELU -> Linear(C/4 -> C) applied on NCHW (no permute copies)
+            return channel_linear(self.act(self.D_fc1(x)), self.D_fc2)
         if self.test_id in (1, 2):
             x = x.flatten(2).permute(0, 2, 1)
         h = self.D_fc1(x)

@@ -464,3 +464,34 @@ def reflect_pad1(x):
     if x.shape[-1] < 3 or x.shape[-2] < 3 or x.dtype not in (_F32, _BF16) or not x.is_cuda:
         return torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect")
     return _ReflectPad1.apply(x)
+
+
+# ---------------------------------------------------------------------------------------------
+# depthwise 3x3 (stride 1 / 2, pad 1) of the stem and the stage transitions   rka.py:414-416, 451-453
+# ---------------------------------------------------------------------------------------------
+class _DwConv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        wf = w.detach().to(_F32).contiguous()
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=x.dtype)
+        call(f"ppea_dwconv3x3_fwd_{_suffix(x)}", ptr(x), ptr(wf), ptr(y), N, C, H, W, stride, stream_ptr())
+        ctx.save_for_backward(wf)
+        ctx.meta = (N, C, H, W, stride, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (wf,) = ctx.saved_tensors
+        N, C, H, W, stride, dt = ctx.meta
+        dy = dy.contiguous().to(dt)
+        dx = torch.empty(N, C, H, W, device=dy.device, dtype=dt)
+        call(f"ppea_dwconv3x3_bwd_data_{_suffix(dy)}", ptr(dy), ptr(wf), ptr(dx), N, C, H, W, stride, stream_ptr())
+        return dx, None, None
+
+
+def dwconv3x3(x, w, stride):
+    """Frozen-filter depthwise 3x3 (no weight gradient: the backbone convs are frozen, repdepth.py:47-50)."""
+    return _DwConv3x3.apply(x, w.detach(), stride)

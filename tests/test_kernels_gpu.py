@@ -329,3 +329,24 @@ def test_reflect_pad1(device, dtype, shape):
     assert torch.equal(y.detach().cpu(), F.pad(x, (1, 1, 1, 1), mode="reflect"))
     (y.float() * go.to(device).float()).sum().backward()
     assert rel_err(xd.grad.float().cpu(), xr.grad) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("shape", [(2, 8, 24, 40), (1, 3, 7, 9), (2, 4, 1, 5)])
+def test_dwconv3x3(device, dtype, stride, shape):
+    import torch.nn.functional as F
+    from ppeadepth import ops
+    N, C, H, W = shape
+    x = torch.randn(shape, generator=_g(H + stride)).to(dtype)
+    w = torch.randn(C, 1, 3, 3, generator=_g(7)) / 3
+    xr = x.float().clone().requires_grad_(True)
+    ref = F.conv2d(xr, w, None, stride, 1, 1, C)
+    go = torch.randn(ref.shape, generator=_g(8)).to(dtype)
+    (ref * go.float()).sum().backward()
+    xd = x.to(device).requires_grad_(True)
+    y = ops.dwconv3x3(xd, w.to(device), stride)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert y.shape == ref.shape and rel_err(y.float().cpu(), ref) < tol
+    (y.float() * go.to(device).float()).sum().backward()
+    assert rel_err(xd.grad.float().cpu(), xr.grad) < tol
