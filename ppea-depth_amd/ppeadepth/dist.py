@@ -47,29 +47,30 @@ def broadcast_module(module, src=0):
 
 
 class FlatGrads:
-    """One contiguous gradient buffer for all trainable parameters + chunked mean all-reduce."""
+    """One contiguous fp32 gradient buffer for the optimizer's tensors + chunked mean all-reduce.
+    `targets[i].grad` is a view into the buffer; `gather(sources)` fills it from the model parameters'
+    freshly produced gradients (bf16 or fp32) with ONE multi-tensor copy."""
 
-    def __init__(self, params, n_chunks=4, dtype=torch.float32):
-        self.params = [p for p in params if p.requires_grad]
-        # reverse registration order ~ order in which backward completes gradients
-        self.params = list(reversed(self.params))
-        device = self.params[0].device
-        self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel, device=device, dtype=dtype)
+    def __init__(self, targets, n_chunks=4):
+        self.targets = list(targets)
+        device = self.targets[0].device
+        self.numel = sum(p.numel() for p in self.targets)
+        self.flat = torch.zeros(self.numel, device=device, dtype=torch.float32)
         off = 0
-        self.offsets = []
-        for p in self.params:
+        self.views = []
+        for p in self.targets:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            self.offsets.append(off)
+            v = self.flat[off:off + n].view_as(p)
+            self.views.append(v)
+            p.grad = v
             off += n
-        n_chunks = max(1, min(n_chunks, len(self.params)))
-        # chunk boundaries on parameter boundaries, ~equal bytes
-        target = self.numel / n_chunks
-        self.bounds = [0]
-        for off_i, p in zip(self.offsets, self.params):
-            if off_i + p.numel() >= target * len(self.bounds) and len(self.bounds) < n_chunks:
-                self.bounds.append(off_i + p.numel())
+        n_chunks = max(1, min(n_chunks, len(self.targets)))
+        target = self.numel / n_chunks                     # chunk boundaries on tensor boundaries
+        self.bounds, acc = [0], 0
+        for p in self.targets:
+            acc += p.numel()
+            if acc >= target * len(self.bounds) and len(self.bounds) < n_chunks:
+                self.bounds.append(acc)
         if self.bounds[-1] != self.numel:
             self.bounds.append(self.numel)
         self.comm_stream = torch.cuda.Stream(device) if device.type == "cuda" else None
@@ -77,32 +78,22 @@ class FlatGrads:
     def zero(self):
         self.flat.zero_()
 
-    def rebind(self):
-        """Re-attach the views (an optimizer's zero_grad(set_to_none=True) would drop them)."""
-        for p, off in zip(self.params, self.offsets):
-            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
-                p.grad = self.flat[off:off + p.numel()].view_as(p)
-
-    def gather_and_all_reduce(self):
-        """Pack the freshly produced gradients into the flat buffer with ONE multi-tensor copy, all-reduce
-        the buffer in a few large chunks, and hand the views back to the optimizer."""
-        views, grads = [], []
-        for p, off in zip(self.params, self.offsets):
-            v = self.flat[off:off + p.numel()].view_as(p)
-            views.append(v)
+    def gather(self, sources):
+        """views[i] <- sources[i].grad (zero where a parameter received no gradient)."""
+        dst, src = [], []
+        for v, p in zip(self.views, sources):
             if p.grad is None:
                 v.zero_()
-            else:
-                grads.append((v, p.grad))
-        if grads:
-            torch._foreach_copy_([v for v, _ in grads], [g for _, g in grads])
-        for p, v in zip(self.params, views):
-            p.grad = v
-        self.all_reduce_mean()
+            elif p.grad.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for t, v in zip(self.targets, self.views):
+            t.grad = v
 
     def all_reduce_mean(self):
-        """Mean over ranks (DDP semantics).  Call after backward; returns when the reduced gradients
-        are visible to the current stream."""
+        """Mean over ranks (DDP semantics) in a few large chunks on a side stream."""
         w = world_size()
         if w == 1:
             return
@@ -131,23 +122,23 @@ class TrainEngine:
         if bf16_params:
             self._to_bf16_params(model)
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.grads = FlatGrads(self.params, n_chunks=n_chunks)
+        # reverse registration order ~ the order in which backward finishes the gradients
+        self.params = list(reversed(self.params))
         lr = trainer.opt.learning_rate if lr is None else lr
         on_gpu = self.params[0].is_cuda
         if fused_adam is None:
             fused_adam = on_gpu
-        opt_params = self.params
-        if self.masters is not None:
-            # fp32 master copy per bf16 parameter (others are their own master); Adam runs on the masters
-            opt_params = [self.masters.get(id(p), p) for p in self.params]
-            self._lo = [p for p in self.params if id(p) in self.masters]
-            self._hi = [self.masters[id(p)] for p in self._lo]
+        # the tensors Adam updates: the fp32 master of a bf16 parameter, else the parameter itself
+        self.opt_params = [self.masters.get(id(p), p) for p in self.params] if self.masters else self.params
+        self._lo = [p for p in self.params if self.masters and id(p) in self.masters]
+        self._hi = [self.masters[id(p)] for p in self._lo]
+        self.flat = FlatGrads(self.opt_params, n_chunks) if world_size() > 1 else None
+        if self.flat is None and self._lo:
             self._hi_grads = [torch.zeros_like(m) for m in self._hi]
             for m, g in zip(self._hi, self._hi_grads):
                 m.grad = g
-        self.opt_params = opt_params
-        self.optimizer = torch.optim.Adam(opt_params, lr, fused=True, capturable=on_gpu) if fused_adam else \
-            torch.optim.Adam(opt_params, lr, foreach=True)
+        self.optimizer = torch.optim.Adam(self.opt_params, lr, fused=True, capturable=on_gpu) if fused_adam else \
+            torch.optim.Adam(self.opt_params, lr, foreach=True)
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, trainer.opt.scheduler_step_size, 0.1)
         self.graph = None
         self.static_inputs = None
@@ -231,28 +222,18 @@ class TrainEngine:
 
     def _step_body(self, inputs):
         outputs, losses = self.trainer.process_batch(inputs, is_train=True)
-        if world_size() == 1:
-            # one rank: gradients stay where autograd puts them (no 1 306 accumulate-into-view kernels);
-            # the fused multi-tensor Adam reads the list directly
-            for p in self.params:
-                p.grad = None
-            losses["loss"].backward()
-        else:
-            for p in self.params:
-                p.grad = None
-            losses["loss"].backward()
-            self.grads.gather_and_all_reduce()
-        if self.masters is not None:
-            if self._lo:
-                torch._foreach_copy_(self._hi_grads, [p.grad for p in self._lo])     # bf16 grads -> fp32
-            for p in self.params:
-                if id(p) not in self.masters:
-                    pass                                                             # own master: p.grad used as is
-            self.optimizer.step()
-            if self._lo:
-                torch._foreach_copy_(self._lo, self._hi)                             # masters -> bf16 weights
-        else:
-            self.optimizer.step()
+        for p in self.params:
+            p.grad = None              # autograd then hands each gradient over without an accumulate kernel
+        losses["loss"].backward()
+        if self.flat is not None:      # several ranks: pack -> few large all-reduces -> Adam on the views
+            self.flat.gather(self.params)
+            self.flat.all_reduce_mean()
+        elif self._lo:                 # one rank, bf16 working weights: bf16 grads -> fp32 master grads
+            torch._foreach_copy_(self._hi_grads, [p.grad if p.grad is not None else torch.zeros_like(p)
+                                                  for p in self._lo])
+        self.optimizer.step()
+        if self._lo:
+            torch._foreach_copy_(self._lo, self._hi)      # masters -> bf16 working weights
         return outputs, losses
 
     def step(self, inputs):

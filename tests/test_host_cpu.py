@@ -167,9 +167,11 @@ def _dp_worker(rank, world, port, q):
     flat = pdist.FlatGrads(params, n_chunks=3)
     torch.manual_seed(100 + rank)                        # different data per rank
     x = torch.randn(5, 8)
-    flat.zero()
+    for p in params:
+        p.grad = None
     model(x).pow(2).sum().backward()
     local = [p.grad.clone() for p in params]
+    flat.gather(params)
     flat.all_reduce_mean()
     gathered = [torch.zeros_like(torch.cat([g.reshape(-1) for g in local])) for _ in range(world)]
     dist.all_gather(gathered, torch.cat([g.reshape(-1) for g in local]))
