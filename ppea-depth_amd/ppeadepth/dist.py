@@ -229,11 +229,13 @@ class TrainEngine:
             self.flat.gather(self.params)
             self.flat.all_reduce_mean()
         elif self._lo:                 # one rank, bf16 working weights: bf16 grads -> fp32 master grads
-            torch._foreach_copy_(self._hi_grads, [p.grad if p.grad is not None else torch.zeros_like(p)
-                                                  for p in self._lo])
+            with torch.no_grad():
+                torch._foreach_copy_(self._hi_grads, [p.grad if p.grad is not None else torch.zeros_like(p)
+                                                      for p in self._lo])
         self.optimizer.step()
         if self._lo:
-            torch._foreach_copy_(self._lo, self._hi)      # masters -> bf16 working weights
+            with torch.no_grad():
+                torch._foreach_copy_(self._lo, self._hi)  # masters -> bf16 working weights
         return outputs, losses
 
     def step(self, inputs):
