@@ -17,6 +17,7 @@ from .. import ops, rng
 from ..batchnorm import BatchNorm2d, fused_bn_act
 
 FUSE_BN = True      # training-mode BN + activation + residual glue on the fused HIP kernels
+ADAPTER_CHANNELS_LAST = True
 
 use_sync_bn = False
 
@@ -131,9 +132,12 @@ def fuse_bn(conv, bn):
 def channel_linear(x, lin):
     """nn.Linear `lin` applied over the channel axis of x [B,C,H,W] -> [B,C_out,H,W]."""
     B, C, H, W = x.shape
-    y = torch.matmul(lin.weight, x.flatten(2))
+    w = lin.weight.unsqueeze(0).expand(B, -1, -1)          # stride-0 batch: one strided-batched GEMM, no copy
+    xf = x.flatten(2)
     if lin.bias is not None:
-        y = y + lin.bias[:, None]
+        y = torch.baddbmm(lin.bias[None, :, None], w, xf)
+    else:
+        y = torch.bmm(w, xf)
     return y.view(B, -1, H, W)
 
 
@@ -174,7 +178,14 @@ class B_Adapter(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
-        if self.test_id == 4:      # Conv3x3 -> GELU -> Linear(C/4 -> C) applied on NCHW (no permute copies)
+        if self.test_id == 4:
+            if ADAPTER_CHANNELS_LAST and x.is_cuda:
+                # whole branch in NHWC: MIOpen's implicit-GEMM kernels are NHWC-native (no per-conv layout
+                # round trips), and Linear over channels is then a plain [B*HW, C/4] x [C/4, C] GEMM
+                xc = x.contiguous(memory_format=torch.channels_last)
+                h = self.act(self.D_fc1(xc))                                   # [B,C/4,H,W] channels_last
+                y = F.linear(h.permute(0, 2, 3, 1), self.D_fc2.weight, self.D_fc2.bias)    # [B,H,W,C]
+                return y.permute(0, 3, 1, 2).contiguous()
             return channel_linear(self.act(self.D_fc1(x)), self.D_fc2)
         if self.test_id in (1, 2):
             x = x.flatten(2).permute(0, 2, 1)
