@@ -85,7 +85,7 @@ class _SyncBNFn(torch.autograd.Function):
         packed = torch.cat([mean, invstd, mean.new_full((1,), float(count))])
         world = dist.get_world_size(group)
         gathered = torch.empty(world, 2 * C + 1, device=x.device, dtype=packed.dtype)
-        dist.all_gather_into_tensor(gathered, packed, group=group)
+        dist.all_gather(list(gathered.unbind(0)), packed, group=group)
         mean_all, invstd_all, counts = gathered[:, :C], gathered[:, C:2 * C], gathered[:, 2 * C]
         mean, invstd = torch.batch_norm_gather_stats_with_counts(
             x, mean_all, invstd_all, running_mean, running_var, momentum, eps, counts)
@@ -124,7 +124,7 @@ def _global_stats(bn, z):
     world = dist.get_world_size()
     packed = torch.cat([mean_l, var_l, mean_l.new_full((1,), float(cnt))])
     gathered = torch.empty(world, 2 * C + 1, device=z.device, dtype=packed.dtype)
-    dist.all_gather_into_tensor(gathered, packed)
+    dist.all_gather(list(gathered.unbind(0)), packed)         # list form: works on RCCL and on gloo
     means, vars_, counts = gathered[:, :C], gathered[:, C:2 * C], gathered[:, 2 * C:2 * C + 1]
     total = counts.sum()
     mean = (means * counts).sum(0) / total
