@@ -120,7 +120,12 @@ def main():
     engine.step(dict(inputs))
     barrier()
     events, ops.PROFILE_DWCONV = ops.PROFILE_DWCONV, None
-    if not args.eager:
+    # Several ranks: the captured graph would contain several hundred RCCL collectives (SyncBN statistics)
+    # plus the gradient all-reduce on a side stream; that path cannot be exercised on the one-GPU
+    # development box, so it is opt-in (PPEA_MULTI_GRAPH=1) and the default for N > 1 is eager launches.
+    use_graph = (not args.eager) and (world == 1 or os.environ.get("PPEA_MULTI_GRAPH") == "1")
+    args.eager = not use_graph
+    if use_graph:
         engine.capture(inputs, warmup=1)
         for _ in range(2):
             engine.step(inputs)
