@@ -81,6 +81,16 @@ int ppea_dwconv_lk_bwd_filter_f32(const float* x, const float* dy, float* dw,
                                   int N, int C, int H, int W, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * A5/A6  Pointwise (1x1) convolution on MFMA, NCHW bf16 (csrc/pwconv.hip): RepLKBlock.pw1/pw2,
+ *     ConvFFN.pw1/pw2, stem[2], transitions[.][0] (replknet_adapter.py:270-271, 296-297, 415, 452).
+ *     Y[b][m][p] = sum_k A[m][k] * X[b][k][p] (+ bias[m]);  A [M][K] bf16 row-major = the conv weight
+ *     [Cout][Cin] for forward, its transpose for the data gradient.  X [B][K][HW], Y [B][M][HW].
+ *     Fast path needs K % 32 == 0 and HW % 8 == 0; otherwise PPEA_ERR_UNSUPPORTED.
+ * ---------------------------------------------------------------------------------------- */
+int ppea_pwconv_bf16(const void* A, const void* X, const float* bias, void* Y, int B, int M, int K, int HW,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * A2 (+A5/A6 glue)  Training-mode BatchNorm fused with its neighbours (csrc/bn_fused.hip):
  *     y = act( BN_a(z1) [+ BN_b(z2)] ) [* mask[n]] [+ r1] [+ r2_scale * r2]
  *   replaces conv_bn / conv_bn_relu (replknet_adapter.py:182-197), the two-branch sum of

@@ -1,0 +1,170 @@
+// Pointwise (1x1) convolution on the matrix cores, NCHW bf16 in / fp32 accumulate / bf16 out, gfx950.
+// Replaces the 1x1 nn.Conv2d of RepLKBlock / ConvFFN / stem[2] / transitions[.][0]
+// (networks/replknet_adapter.py:270-271, 296-297, 415, 452) in forward and, with the transposed
+// weight matrix, their data gradients.
+//
+//     Y[n][m][p] = sum_k A[m][k] * X[n][k][p] (+ bias[m])        A = W [Cout][Cin]  (or W^T for dgrad)
+//
+// Per image a GEMM with the activation operand in its natural NCHW form: k (channel) is the SLOW axis
+// of X, pixels are contiguous.  The tile of X is staged into LDS exactly as it lies in memory
+// ([32 channels][128 pixels], coalesced 16-byte reads, no transposition) and the MFMA B fragments
+// (8 consecutive k for one pixel) come out of `ds_read_b64_tr_b16`, the CDNA4 transposing LDS read.
+//   * block = 4 waves, tile BM x 128 pixels, BK = 32; `v_mfma_f32_16x16x32_bf16`;
+//   * A tile [BM][32] with a 96-byte row stride, B tile XOR-swizzled in 8-byte chunks: both fragment
+//     reads are bank-conflict free (cdna_hip_programming.md 2, T10);
+//   * global -> register prefetch of the next K-tile overlaps the MFMAs of the current one.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+constexpr int BN = 128, BK = 32;
+constexpr int A_STRIDE = 96;                    // bytes per A row in LDS (64 data + 32 pad)
+constexpr int B_STRIDE = 256;                   // bytes per B row (128 pixels), swizzled
+
+__device__ __forceinline__ int b_swz(int row) { return 4 * (row & 3) + 16 * ((row >> 3) & 1); }
+
+template <int BM, int WM, int WN>
+__global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ X,
+                                                     const float* __restrict__ bias, uint16_t* __restrict__ Y, int M,
+                                                     int K, int HW) {
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
+    constexpr int A_BYTES = BM * A_STRIDE, B_BYTES = BK * B_STRIDE;
+    constexpr int A_CH = (BM * 4 + 255) / 256;  // 16-byte chunks of the A tile per thread
+    __shared__ __attribute__((aligned(16))) uint8_t lds[A_BYTES + B_BYTES];
+    uint8_t* As = lds;
+    uint8_t* Bs = lds + A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int p0 = blockIdx.x * BN, m0 = blockIdx.y * BM, n = blockIdx.z;
+    const uint16_t* Xn = X + (long)n * K * HW;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+
+    // per-thread staging coordinates
+    int a_row[A_CH], a_ch[A_CH];
+#pragma unroll
+    for (int c = 0; c < A_CH; ++c) { const int idx = tid + c * 256; a_row[c] = idx >> 2; a_ch[c] = idx & 3; }
+    int b_row[2], b_c16[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { const int idx = tid + c * 256; b_row[c] = idx >> 4; b_c16[c] = idx & 15; }
+
+    uint4 a_reg[A_CH], b_reg[2];
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int c = 0; c < A_CH; ++c) {
+            const int m = m0 + a_row[c];
+            a_reg[c] = (m < M && a_row[c] < BM) ? *reinterpret_cast<const uint4*>(A + (long)m * K + k0 + a_ch[c] * 8)
+                                                : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int p = p0 + b_c16[c] * 8;
+            b_reg[c] = (p < HW) ? *reinterpret_cast<const uint4*>(Xn + (long)(k0 + b_row[c]) * HW + p)
+                                : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int c = 0; c < A_CH; ++c)
+            if (a_row[c] < BM) *reinterpret_cast<uint4*>(As + a_row[c] * A_STRIDE + a_ch[c] * 16) = a_reg[c];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int s = b_swz(b_row[c]);
+            uint8_t* rowp = Bs + b_row[c] * B_STRIDE;
+            *reinterpret_cast<uint2*>(rowp + (((2 * b_c16[c]) ^ s) << 3)) = make_uint2(b_reg[c].x, b_reg[c].y);
+            *reinterpret_cast<uint2*>(rowp + (((2 * b_c16[c] + 1) ^ s) << 3)) = make_uint2(b_reg[c].z, b_reg[c].w);
+        }
+    };
+
+    // fragment addresses
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const uint8_t* a_frag = As + (wm * TM + li) * A_STRIDE + g * 16;
+    const int b_rowi = 8 * g + q;
+    const uint8_t* b_frag = Bs + b_rowi * B_STRIDE;
+    const int b_s = b_swz(b_rowi);
+
+    load_tiles(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        __syncthreads();                          // previous tile's fragment reads are done
+        store_tiles();
+        __syncthreads();
+        if (k0 + BK < K) load_tiles(k0 + BK);     // prefetch while the MFMAs run
+        bf16x8 af[MT], bfr[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_frag + i * 16 * A_STRIDE));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int chunk = (((wn * TN + 16 * j) >> 2) + pp) ^ b_s;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b_frag + (chunk << 3)));
+            const s16x4 hi =
+                __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b_frag + 4 * B_STRIDE + (chunk << 3)));
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            bfr[j] = __builtin_bit_cast(bf16x8, both);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+
+    // epilogue: C layout col = lane & 15 (pixel), row = 4 * (lane >> 4) + r (output channel)
+    uint16_t* Yn = Y + (long)n * M * HW;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * TM + 16 * i + 4 * g + r;
+            if (m >= M) continue;
+            const float bv = (bias != nullptr) ? bias[m] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int p = p0 + wn * TN + 16 * j + li;
+                if (p < HW) Yn[(long)m * HW + p] = __builtin_bit_cast(uint16_t, (__bf16)(acc[i][j][r] + bv));
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+// A [M][K] bf16 row-major (k contiguous); X [B][K][HW] bf16; Y [B][M][HW] bf16; bias [M] fp32 or NULL.
+// Requirements of the fast path: K % 32 == 0, HW % 8 == 0 (else PPEA_ERR_UNSUPPORTED).
+int ppea_pwconv_bf16(const void* A, const void* X, const float* bias, void* Y, int B, int M, int K, int HW,
+                     void* stream) {
+    if (B <= 0 || M <= 0 || K <= 0 || HW <= 0 || (K % BK) != 0 || (HW % 8) != 0 || B > 65535)
+        return PPEA_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (HW + BN - 1) / BN;
+    const long blocks128 = (long)nb * ((M + 127) / 128) * B;
+    if (M >= 128 && blocks128 >= 512) {
+        dim3 g(nb, (M + 127) / 128, B);
+        hipLaunchKernelGGL((pwconv_kernel<128, 2, 2>), g, dim3(256), 0, st, (const uint16_t*)A, (const uint16_t*)X,
+                           bias, (uint16_t*)Y, M, K, HW);
+    } else if (M > 32) {
+        dim3 g(nb, (M + 63) / 64, B);
+        hipLaunchKernelGGL((pwconv_kernel<64, 2, 2>), g, dim3(256), 0, st, (const uint16_t*)A, (const uint16_t*)X,
+                           bias, (uint16_t*)Y, M, K, HW);
+    } else {
+        dim3 g(nb, (M + 31) / 32, B);
+        hipLaunchKernelGGL((pwconv_kernel<32, 1, 4>), g, dim3(256), 0, st, (const uint16_t*)A, (const uint16_t*)X,
+                           bias, (uint16_t*)Y, M, K, HW);
+    }
+    return launch_status();
+}
+
+}  // extern "C"

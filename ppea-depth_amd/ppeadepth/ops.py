@@ -495,3 +495,55 @@ class _DwConv3x3(torch.autograd.Function):
 def dwconv3x3(x, w, stride):
     """Frozen-filter depthwise 3x3 (no weight gradient: the backbone convs are frozen, repdepth.py:47-50)."""
     return _DwConv3x3.apply(x, w.detach(), stride)
+
+
+# ---------------------------------------------------------------------------------------------
+# A5/A6  pointwise conv on MFMA (frozen 1x1 convs: forward with W, data gradient with W^T)
+# ---------------------------------------------------------------------------------------------
+_PW_CACHE = {}
+
+
+def _pw_matrices(w):
+    """(W [Cout][Cin] bf16, W^T [Cin][Cout] bf16) of a frozen 1x1 conv weight, cached per version."""
+    key = (w.data_ptr(), w.device.index)
+    hit = _PW_CACHE.get(key)
+    if hit is not None and hit[0] == w._version and hit[3] == tuple(w.shape):
+        return hit[1], hit[2]
+    m = w.detach().reshape(w.shape[0], w.shape[1]).to(_BF16).contiguous()
+    mt = m.t().contiguous()
+    _PW_CACHE[key] = (w._version, m, mt, tuple(w.shape))
+    return m, mt
+
+
+def pwconv_raw(a_mat, x, bias=None):
+    """Y[b] = A @ X[b] (+ bias) for x [B,K,H,W] bf16, A [M,K] bf16 -> [B,M,H,W]; None if unsupported."""
+    B, K, H, W = x.shape
+    M = a_mat.shape[0]
+    y = torch.empty(B, M, H, W, device=x.device, dtype=_BF16)
+    err = _abi.lib.ppea_pwconv_bf16(ptr(a_mat, _BF16), ptr(x, _BF16), ptr(bias), ptr(y), B, M, K, H * W, stream_ptr())
+    if err == -1:
+        return None
+    _abi.check(err, "ppea_pwconv_bf16")
+    return y
+
+
+class _PwConvFrozen(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        a, at = _pw_matrices(w)
+        y = pwconv_raw(a, x.contiguous())
+        ctx.at = at
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return pwconv_raw(ctx.at, dy.contiguous().to(_BF16)), None
+
+
+def pwconv_frozen(x, w):
+    """1x1 conv with a frozen weight [Cout,Cin,1,1] on the MFMA kernel; None when the shape is not served
+    (caller falls back to the library conv)."""
+    B, K, H, W = x.shape
+    if x.dtype != _BF16 or not x.is_cuda or K % 32 != 0 or (H * W) % 8 != 0 or w.requires_grad:
+        return None
+    return _PwConvFrozen.apply(x, w)

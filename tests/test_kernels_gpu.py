@@ -350,3 +350,26 @@ def test_dwconv3x3(device, dtype, stride, shape):
     assert y.shape == ref.shape and rel_err(y.float().cpu(), ref) < tol
     (y.float() * go.to(device).float()).sum().backward()
     assert rel_err(xd.grad.float().cpu(), xr.grad) < tol
+
+
+@pytest.mark.parametrize("B,M,K,H,W", [(2, 128, 128, 48, 160), (3, 512, 128, 12, 40), (2, 64, 256, 24, 80),
+                                       (2, 32, 128, 6, 20), (1, 200, 96, 5, 8), (2, 1024, 256, 6, 20)])
+def test_pwconv_mfma(device, B, M, K, H, W):
+    """1x1 conv on MFMA (transposing LDS reads) vs fp32 matmul of the bf16-rounded operands, with bias;
+    autograd wrapper: data gradient through the transposed matrix."""
+    from ppeadepth import ops
+    g = _g(M + K)
+    x = torch.randn(B, K, H, W, generator=g).bfloat16()
+    w = (torch.randn(M, K, 1, 1, generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn(M, generator=g)
+    ref = torch.einsum("mk,bkhw->bmhw", w.float().view(M, K), x.float()) + bias.view(1, -1, 1, 1)
+    y = ops.pwconv_raw(w.view(M, K).contiguous().to(device), x.to(device), bias.to(device))
+    assert y is not None
+    assert (y.float().cpu() - ref).abs().max() <= ref.abs().max() * 2 ** -7
+    xd = x.to(device).requires_grad_(True)
+    wd = w.to(device)
+    y2 = ops.pwconv_frozen(xd, wd)
+    go = torch.randn(B, M, H, W, generator=g).bfloat16()
+    y2.backward(go.to(device))
+    gref = torch.einsum("mk,bmhw->bkhw", w.float().view(M, K), go.float())
+    assert (xd.grad.float().cpu() - gref).abs().max() <= gref.abs().max() * 2 ** -7
