@@ -84,8 +84,25 @@ class SmallDW(nn.Conv2d):
         return super().forward(x)
 
 
+class PointwiseConv(nn.Conv2d):
+    """1x1 stride-1 conv; frozen + bf16 activations run on the NCHW MFMA kernel (forward with W, data
+    gradient with W^T), everything else on the library conv."""
+
+    def forward(self, x):
+        if PW_MFMA and x.is_cuda and x.dtype == torch.bfloat16 and not self.weight.requires_grad:
+            y = ops.pwconv_frozen(x, self.weight)
+            if y is not None:
+                return y
+        return super().forward(x)
+
+
+PW_MFMA = True
+
+
 def get_conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias):
     k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+    if k == 1 and stride == 1 and padding == 0 and groups == 1 and dilation == 1 and not bias:
+        return PointwiseConv(in_channels, out_channels, 1, 1, 0, 1, 1, False)
     if (in_channels == out_channels == groups and k == 3 and stride in (1, 2) and padding == 1 and dilation == 1
             and groups > 1):
         return SmallDW(in_channels, out_channels, 3, stride, 1, 1, groups, bias)

@@ -544,6 +544,7 @@ def pwconv_frozen(x, w):
     """1x1 conv with a frozen weight [Cout,Cin,1,1] on the MFMA kernel; None when the shape is not served
     (caller falls back to the library conv)."""
     B, K, H, W = x.shape
-    if x.dtype != _BF16 or not x.is_cuda or K % 32 != 0 or (H * W) % 8 != 0 or w.requires_grad:
+    if (x.dtype != _BF16 or not x.is_cuda or K % 32 != 0 or w.shape[0] % 32 != 0 or (H * W) % 8 != 0
+            or w.requires_grad):
         return None
     return _PwConvFrozen.apply(x, w)

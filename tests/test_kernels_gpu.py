@@ -369,6 +369,9 @@ def test_pwconv_mfma(device, B, M, K, H, W):
     xd = x.to(device).requires_grad_(True)
     wd = w.to(device)
     y2 = ops.pwconv_frozen(xd, wd)
+    if M % 32:                                  # the data gradient contracts over M: not served, caller falls back
+        assert y2 is None
+        return
     go = torch.randn(B, M, H, W, generator=g).bfloat16()
     y2.backward(go.to(device))
     gref = torch.einsum("mk,bmhw->bkhw", w.float().view(M, K), go.float())

@@ -31,5 +31,9 @@ for (B, Ci, H, W, Co) in shapes:
                           timeit(lambda: torch.autograd.grad(torch.matmul(w2, x.flatten(2)), x, gy.flatten(2))))
     res["conv_cl"] = (timeit(lambda: F.conv2d(xcl, w)), timeit(lambda: torch.autograd.grad(F.conv2d(xcl, w), xcl, gycl)))
     res["matmul_nhwc"] = (timeit(lambda: xn @ w2.t()), timeit(lambda: torch.autograd.grad(xn @ w2.t(), xn, gyn)))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ppea-depth_amd"))
+    from ppeadepth import ops
+    w2c = w2.contiguous(); xd = x.detach()
+    res["hip_pw"] = (timeit(lambda: ops.pwconv_raw(w2c, xd)), 0.0)
     print(f"[{B},{Ci},{H},{W}]->{Co}  " + "  ".join(
         f"{k}: f {a:7.1f}us ({fl/a/1e6:5.0f}TF) f+b {b:7.1f}us" for k, (a, b) in res.items()), flush=True)
