@@ -33,6 +33,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TF = 157.3        # fp32 vector peak
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak
 
 
 def cpu_baseline(seconds_budget=40.0):
@@ -153,16 +154,28 @@ def main():
             t_k = sum(fwd) / len(fwd)
             plane = B * C0 * 48 * 160
             bytes_alg = plane * es * 3 + C0 * (961 + 25) * 4            # x in, y_big + y_small out, weights
-            flops = 2.0 * plane * (961 + 25)
-            roof = {"kernel": "dwconv_lk_kernel<k=31,+5x5 fused> fwd", "bound": "hbm",
-                    "achieved": round(bytes_alg / t_k / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(bytes_alg / t_k / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            useful = 2.0 * plane * (961 + 25)
+            roof = {"kernel": "31x31 depthwise conv fwd (+ fused 5x5 branch), stage-0 planes [%d,%d,48,160]" % (B, C0),
+                    "bound": "hbm", "achieved": round(bytes_alg / t_k / 1e9, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(bytes_alg / t_k / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_launch_us": round(t_k * 1e6, 1), "launches_timed": len(fwd),
                     "algorithmic_bytes_per_launch": bytes_alg,
-                    "binding_roof": "fp32 vector FMA (AI ~ %d F/B)" % round(flops / bytes_alg),
-                    "valu_tflops": round(flops / t_k / 1e12, 1),
-                    "valu_frac": round(flops / t_k / 1e12 / VALU_PEAK_TF, 3),
                     "dgrad_avg_launch_us": round(sum(bwd) / len(bwd) * 1e6, 1) if bwd else None}
+            if args.dtype == "bf16":
+                # banded-Toeplitz MFMA kernel: (31 rows x 2 chunks + 5) v_mfma_f32_16x16x32_bf16 per 16x16 tile
+                executed = (plane / 256.0) * (31 * 2 + 5) * 2.0 * 16 * 16 * 32
+                roof.update({"name": "dwconv_mfma_kernel<31,5,0,5>",
+                             "binding_roof": "bf16 MFMA (useful AI %d F/B; Toeplitz band executes %.2fx the useful MACs)"
+                                             % (round(useful / bytes_alg), executed / useful),
+                             "mfma_executed_tflops": round(executed / t_k / 1e12, 1),
+                             "mfma_useful_tflops": round(useful / t_k / 1e12, 1),
+                             "mfma_peak_tflops": MFMA_BF16_PEAK_TF,
+                             "mfma_frac": round(executed / t_k / 1e12 / MFMA_BF16_PEAK_TF, 3)})
+            else:
+                roof.update({"name": "dwconv_lk_kernel<float,31,5,...>",
+                             "binding_roof": "fp32 vector FMA (AI ~ %d F/B)" % round(useful / bytes_alg),
+                             "valu_tflops": round(useful / t_k / 1e12, 1),
+                             "valu_frac": round(useful / t_k / 1e12 / VALU_PEAK_TF, 3)})
         line = {
             "metric": "training img/s at 640x192 RepLKNet-31B" if args.rep_size == "b" else
                       "training img/s at 640x192 RepLKNet-31L",
