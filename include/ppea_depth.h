@@ -24,6 +24,7 @@ extern "C" {
 #endif
 
 #define PPEA_ERR_UNSUPPORTED (-1)
+#define PPEA_ERR_ARG (-2)          /* inconsistent arguments (e.g. a required pointer is NULL) */
 
 /* Library / build identification: returns the ABI version (bumped on any signature change). */
 int ppea_abi_version(void);
@@ -89,6 +90,32 @@ int ppea_dwconv_lk_bwd_filter_f32(const float* x, const float* dy, float* dw,
  * ---------------------------------------------------------------------------------------- */
 int ppea_pwconv_bf16(const void* A, const void* X, const float* bias, void* Y, int B, int M, int K, int HW,
                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * A4  Adapters (replknet_adapter.py:20-47 `Adapter`: Linear -> GELU -> Linear over channels;
+ *     :49-109 `B_Adapter`, adpt_test 4: Conv2d(C, C/4, 3, 1, 1) -> GELU -> Linear(C/4, C)), forward and
+ *     all gradients, NCHW bf16 end to end (no layout changes), built from four entry points:
+ *
+ *   ppea_pwconv_ex_bf16   the GEMM above with an epilogue. epi 0: Y = A X + bias.  epi 1: Y = pre-activation,
+ *                         Y2 = GELU(pre).  epi 2: Y = (A X) * GELU'(aux)  (aux, Y, Y2: [B][M][HW] bf16).
+ *                         bias: fp32, or bf16 when bias_bf16 != 0.
+ *   ppea_pwgrad_bf16      weight gradients: out[m*N + n] = sum_{b,p} P[b][m][p] Q[b][n][p] (fp32), followed by
+ *                         the row sums of P (bias gradient) at out[M*N + m] when want_rowsum != 0.
+ *                         P [B][M][HW], Q [B][N][HW] bf16, HW % 8 == 0.  `workspace`: device scratch of
+ *                         ppea_pwgrad_workspace_bytes(B, M, N, HW) bytes (split-K partials; deterministic).
+ *   ppea_tapsum_fwd_bf16  the 3x3 conv = GEMM with the tap-major weight matrix [9*Ch][C] (rows t*Ch + m,
+ *                         t = 3*ky + kx) followed by this shift-and-add: pre[b][m][y][x] = bias[m] +
+ *                         sum_t T[b][t*Ch+m][y+ky-1][x+kx-1] (zero padded), h = GELU(pre).  W % 4 == 0.
+ *   ppea_tapsum_bwd_bf16  its adjoint: dT[b][t*Ch+m][y][x] = g[b][m][y-ky+1][x-kx+1].
+ * ---------------------------------------------------------------------------------------- */
+int ppea_pwconv_ex_bf16(const void* A, const void* X, const void* bias, int bias_bf16, int epi, const void* aux,
+                        void* Y, void* Y2, int B, int M, int K, int HW, void* stream);
+long ppea_pwgrad_workspace_bytes(int B, int M, int N, int HW);
+int ppea_pwgrad_bf16(const void* P, const void* Q, float* out, void* workspace, int B, int M, int N, int HW,
+                     int want_rowsum, void* stream);
+int ppea_tapsum_fwd_bf16(const void* T, const void* bias, int bias_bf16, void* pre, void* h, int B, int Ch, int H,
+                         int W, void* stream);
+int ppea_tapsum_bwd_bf16(const void* g, void* dT, int B, int Ch, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A2 (+A5/A6 glue)  Training-mode BatchNorm fused with its neighbours (csrc/bn_fused.hip):

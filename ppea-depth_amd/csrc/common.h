@@ -5,6 +5,7 @@
 
 #define PPEA_ABI_VERSION 1
 #define PPEA_ERR_UNSUPPORTED (-1)
+#define PPEA_ERR_ARG (-2)
 #define WAVE 64
 
 // bf16 <-> f32 (storage type uint16_t).  Plain casts through __hip_bfloat16 would pull in

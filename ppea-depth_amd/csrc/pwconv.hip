@@ -28,10 +28,20 @@ constexpr int B_STRIDE = 256;                   // bytes per B row (128 pixels),
 
 __device__ __forceinline__ int b_swz(int row) { return 4 * (row & 3) + 16 * ((row >> 3) & 1); }
 
-template <int BM, int WM, int WN>
+__device__ __forceinline__ float bf2f(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// EPI 0: Y = acc + bias.   EPI 1: Y = pre = acc + bias, Y2 = GELU(pre) (pre rounded to bf16 first, like an
+// autocast nn.GELU on the stored tensor).   EPI 2: Y = acc * GELU'(aux[n][m][p]) (data gradient through GELU).
+template <int BM, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ X,
-                                                     const float* __restrict__ bias, uint16_t* __restrict__ Y, int M,
-                                                     int K, int HW) {
+                                                     const void* __restrict__ bias, int bias_bf16,
+                                                     const uint16_t* __restrict__ aux, uint16_t* __restrict__ Y,
+                                                     uint16_t* __restrict__ Y2, int M, int K, int HW) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
     constexpr int A_BYTES = BM * A_STRIDE, B_BYTES = BK * B_STRIDE;
@@ -122,20 +132,47 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
     }
 
     // epilogue: C layout col = lane & 15 (pixel), row = 4 * (lane >> 4) + r (output channel)
-    uint16_t* Yn = Y + (long)n * M * HW;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + wm * TM + 16 * i + 4 * g + r;
             if (m >= M) continue;
-            const float bv = (bias != nullptr) ? bias[m] : 0.f;
+            float bv = 0.f;
+            if (bias != nullptr)
+                bv = bias_bf16 ? bf2f(reinterpret_cast<const uint16_t*>(bias)[m]) : reinterpret_cast<const float*>(bias)[m];
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int p = p0 + wn * TN + 16 * j + li;
-                if (p < HW) Yn[(long)m * HW + p] = __builtin_bit_cast(uint16_t, (__bf16)(acc[i][j][r] + bv));
+                if (p >= HW) continue;
+                const long o = (long)n * M * HW + (long)m * HW + p;
+                if constexpr (EPI == 0) {
+                    Y[o] = f2bf(acc[i][j][r] + bv);
+                } else if constexpr (EPI == 1) {
+                    const uint16_t pre = f2bf(acc[i][j][r] + bv);
+                    Y[o] = pre;
+                    Y2[o] = f2bf(gelu_f(bf2f(pre)));
+                } else {
+                    Y[o] = f2bf(acc[i][j][r] * dgelu_f(bf2f(aux[o])));
+                }
             }
         }
+}
+
+template <int EPI>
+int launch_pw(const void* A, const void* X, const void* bias, int bias_bf16, const void* aux, void* Y, void* Y2, int B,
+              int M, int K, int HW, hipStream_t st) {
+    const int nb = (HW + BN - 1) / BN;
+    const long blocks128 = (long)nb * ((M + 127) / 128) * B;
+#define PW_LAUNCH(BM_, WM_, WN_)                                                                                  \
+    hipLaunchKernelGGL((pwconv_kernel<BM_, WM_, WN_, EPI>), dim3(nb, (M + BM_ - 1) / BM_, B), dim3(256), 0, st, \
+                       (const uint16_t*)A, (const uint16_t*)X, bias, bias_bf16, (const uint16_t*)aux, (uint16_t*)Y, \
+                       (uint16_t*)Y2, M, K, HW)
+    if (M >= 128 && blocks128 >= 512) PW_LAUNCH(128, 2, 2);
+    else if (M > 32) PW_LAUNCH(64, 2, 2);
+    else PW_LAUNCH(32, 1, 4);
+#undef PW_LAUNCH
+    return launch_status();
 }
 
 }  // namespace
@@ -148,23 +185,23 @@ int ppea_pwconv_bf16(const void* A, const void* X, const float* bias, void* Y, i
                      void* stream) {
     if (B <= 0 || M <= 0 || K <= 0 || HW <= 0 || (K % BK) != 0 || (HW % 8) != 0 || B > 65535)
         return PPEA_ERR_UNSUPPORTED;
+    return launch_pw<0>(A, X, bias, 0, nullptr, Y, nullptr, B, M, K, HW, (hipStream_t)stream);
+}
+
+// Same GEMM with an epilogue (adapters, replknet_adapter.py:20-109): epi 0 plain; epi 1 writes the
+// pre-activation to Y and GELU(pre) to Y2; epi 2 multiplies by GELU'(aux) (aux, Y: [B][M][HW] bf16).
+// `bias` is fp32 or, with bias_bf16 != 0, bf16.
+int ppea_pwconv_ex_bf16(const void* A, const void* X, const void* bias, int bias_bf16, int epi, const void* aux,
+                        void* Y, void* Y2, int B, int M, int K, int HW, void* stream) {
+    if (B <= 0 || M <= 0 || K <= 0 || HW <= 0 || (K % BK) != 0 || (HW % 8) != 0 || B > 65535)
+        return PPEA_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int nb = (HW + BN - 1) / BN;
-    const long blocks128 = (long)nb * ((M + 127) / 128) * B;
-    if (M >= 128 && blocks128 >= 512) {
-        dim3 g(nb, (M + 127) / 128, B);
-        hipLaunchKernelGGL((pwconv_kernel<128, 2, 2>), g, dim3(256), 0, st, (const uint16_t*)A, (const uint16_t*)X,
-                           bias, (uint16_t*)Y, M, K, HW);
-    } else if (M > 32) {
-        dim3 g(nb, (M + 63) / 64, B);
-        hipLaunchKernelGGL((pwconv_kernel<64, 2, 2>), g, dim3(256), 0, st, (const uint16_t*)A, (const uint16_t*)X,
-                           bias, (uint16_t*)Y, M, K, HW);
-    } else {
-        dim3 g(nb, (M + 31) / 32, B);
-        hipLaunchKernelGGL((pwconv_kernel<32, 1, 4>), g, dim3(256), 0, st, (const uint16_t*)A, (const uint16_t*)X,
-                           bias, (uint16_t*)Y, M, K, HW);
+    switch (epi) {
+        case 0: return launch_pw<0>(A, X, bias, bias_bf16, nullptr, Y, nullptr, B, M, K, HW, st);
+        case 1: if (!Y2) return PPEA_ERR_ARG; return launch_pw<1>(A, X, bias, bias_bf16, nullptr, Y, Y2, B, M, K, HW, st);
+        case 2: if (!aux) return PPEA_ERR_ARG; return launch_pw<2>(A, X, nullptr, 0, aux, Y, nullptr, B, M, K, HW, st);
     }
-    return launch_status();
+    return PPEA_ERR_ARG;
 }
 
 }  // extern "C"

@@ -33,6 +33,11 @@ SIGNATURES = {
     "ppea_dwconv_lk_fwd_bf16p": [_vp] * 5 + [_i] * 6 + [_vp],
     "ppea_dwconv_lk_bwd_data_bf16p": [_vp] * 5 + [_i] * 6 + [_vp],
     "ppea_pwconv_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_pwconv_ex_bf16": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_pwgrad_workspace_bytes": [_i, _i, _i, _i],
+    "ppea_pwgrad_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ppea_tapsum_fwd_bf16": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_tapsum_bwd_bf16": [_vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_bn_stats_f32": [_vp, _vp, _i, _i, _i, _vp],
     "ppea_bn_stats_bf16": [_vp, _vp, _i, _i, _i, _vp],
     "ppea_bn_finalize_f32": [_vp, _i, _i, _i, _f, _f] + [_vp] * 5 + [_vp],
@@ -106,7 +111,7 @@ def ptr(t, dtype=None):
 
 def check(err, name):
     if err != 0:
-        what = "unsupported argument combination" if err == -1 else f"hipError_t {err}"
+        what = {-1: "unsupported argument combination", -2: "inconsistent arguments"}.get(err, f"hipError_t {err}")
         raise PpeaKernelError(f"{name} failed: {what}")
 
 

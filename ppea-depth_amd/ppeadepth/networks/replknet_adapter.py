@@ -97,6 +97,7 @@ class PointwiseConv(nn.Conv2d):
 
 
 PW_MFMA = True
+ADAPTER_MFMA = True    # adapters (forward + every gradient) on the NCHW MFMA kernels under bf16
 
 
 def get_conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias):
@@ -170,6 +171,8 @@ class Adapter(nn.Module):
         self.D_fc2 = nn.Linear(hidden, D_features)
 
     def forward(self, x):
+        if ADAPTER_MFMA and ops.adapter_supported(x, self.D_fc1.out_features):
+            return ops.mlp_adapter(x, self.D_fc1.weight, self.D_fc1.bias, self.D_fc2.weight, self.D_fc2.bias)
         # Linear over the channel axis of [B,HW,C] == W @ x[B,C,HW] on NCHW: no permute / reshape copies,
         # one strided-batched GEMM per projection (weight broadcast over the batch)
         return channel_linear(self.act(channel_linear(x, self.D_fc1)), self.D_fc2)
@@ -195,6 +198,9 @@ class B_Adapter(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
+        if ADAPTER_MFMA and self.test_id in (1, 2, 4) and ops.adapter_supported(x, self.D_fc2.in_features):
+            fn = ops.conv_adapter if self.test_id == 4 else ops.mlp_adapter
+            return fn(x, self.D_fc1.weight, self.D_fc1.bias, self.D_fc2.weight, self.D_fc2.bias)
         if self.test_id == 4:
             if ADAPTER_CHANNELS_LAST and x.is_cuda:
                 # whole branch in NHWC: MIOpen's implicit-GEMM kernels are NHWC-native (no per-conv layout

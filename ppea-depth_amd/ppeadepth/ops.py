@@ -548,3 +548,131 @@ def pwconv_frozen(x, w):
             or w.requires_grad):
         return None
     return _PwConvFrozen.apply(x, w)
+
+
+# ---------------------------------------------------------------------------------------------
+# A4  adapters on the MFMA kernels, NCHW bf16 end to end (replknet_adapter.py:20-109)
+# ---------------------------------------------------------------------------------------------
+EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
+
+
+def _bias_arg(b):
+    if b is None:
+        return None, 0
+    if b.dtype == _BF16:
+        return ptr(b, _BF16), 1
+    return ptr(b, _F32), 0
+
+
+def pwconv_ex(a_mat, x, bias=None, epi=EPI_NONE, aux=None):
+    """A [M,K] bf16 applied over the channel axis of x [B,K,H,W] bf16 with an epilogue:
+    EPI_NONE -> y;  EPI_GELU -> (pre, gelu(pre));  EPI_DGELU -> (A x) * gelu'(aux)."""
+    B, K, H, W = x.shape
+    M = a_mat.shape[0]
+    y = torch.empty(B, M, H, W, device=x.device, dtype=_BF16)
+    y2 = torch.empty_like(y) if epi == EPI_GELU else None
+    bp, bflag = _bias_arg(bias)
+    call("ppea_pwconv_ex_bf16", ptr(a_mat, _BF16), ptr(x, _BF16), bp, bflag, epi, ptr(aux, _BF16) if aux is not None
+         else None, ptr(y), ptr(y2), B, M, K, H * W, stream_ptr())
+    return (y, y2) if epi == EPI_GELU else y
+
+
+def pwgrad(p, q, want_rowsum=True):
+    """(sum_{b,pixels} p[b,m,:] q[b,n,:]  [M,N] fp32,  sum_{b,pixels} p[b,m,:]  [M] fp32 or None)."""
+    B, M, H, W = p.shape
+    N = q.shape[1]
+    ws = torch.empty(_abi.lib.ppea_pwgrad_workspace_bytes(B, M, N, H * W) // 4, device=p.device, dtype=_F32)
+    out = torch.empty(M * N + M, device=p.device, dtype=_F32)
+    call("ppea_pwgrad_bf16", ptr(p, _BF16), ptr(q, _BF16), ptr(out), ptr(ws), B, M, N, H * W, int(want_rowsum),
+         stream_ptr())
+    return out[:M * N].view(M, N), (out[M * N:] if want_rowsum else None)
+
+
+def tapsum_fwd(T, bias, Ch):
+    B, _, H, W = T.shape
+    pre = torch.empty(B, Ch, H, W, device=T.device, dtype=_BF16)
+    h = torch.empty_like(pre)
+    bp, bflag = _bias_arg(bias)
+    call("ppea_tapsum_fwd_bf16", ptr(T, _BF16), bp, bflag, ptr(pre), ptr(h), B, Ch, H, W, stream_ptr())
+    return pre, h
+
+
+def tapsum_bwd(g):
+    B, Ch, H, W = g.shape
+    dT = torch.empty(B, 9 * Ch, H, W, device=g.device, dtype=_BF16)
+    call("ppea_tapsum_bwd_bf16", ptr(g, _BF16), ptr(dT), B, Ch, H, W, stream_ptr())
+    return dT
+
+
+def adapter_supported(x, hidden):
+    B, C, H, W = x.shape
+    return (x.is_cuda and x.dtype == _BF16 and C % 32 == 0 and hidden % 32 == 0 and (H * W) % 8 == 0
+            and W % 4 == 0)
+
+
+class _MlpAdapterFn(torch.autograd.Function):
+    """`Adapter` (rka.py:20-47): y = W2 gelu(W1 x + b1) + b2 over the channel axis."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x = x.contiguous()
+        w1m, w2m = w1.to(_BF16).contiguous(), w2.to(_BF16).contiguous()
+        pre, h = pwconv_ex(w1m, x, b1, EPI_GELU)
+        y = pwconv_ex(w2m, h, b2)
+        ctx.save_for_backward(x, pre, h, w1m, w2m)
+        ctx.dtypes = (w1.dtype, b1.dtype, w2.dtype, b2.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pre, h, w1m, w2m = ctx.saved_tensors
+        dy = dy.contiguous()
+        g = pwconv_ex(w2m.t().contiguous(), dy, None, EPI_DGELU, pre)
+        dw2, db2 = pwgrad(dy, h)
+        dw1, db1 = pwgrad(g, x)
+        dx = pwconv_ex(w1m.t().contiguous(), g) if ctx.needs_input_grad[0] else None
+        t = ctx.dtypes
+        return dx, dw1.to(t[0]), db1.to(t[1]), dw2.to(t[2]), db2.to(t[3])
+
+
+class _ConvAdapterFn(torch.autograd.Function):
+    """`B_Adapter`, adpt_test 4 (rka.py:49-109): y = W2 gelu(conv3x3(x; W1) + b1) + b2."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x = x.contiguous()
+        Ch, C = w1.shape[0], w1.shape[1]
+        a1 = w1.to(_BF16).permute(2, 3, 0, 1).reshape(9 * Ch, C).contiguous()     # rows t*Ch + m
+        w2m = w2.to(_BF16).contiguous()
+        T = pwconv_ex(a1, x)
+        pre, h = tapsum_fwd(T, b1, Ch)
+        y = pwconv_ex(w2m, h, b2)
+        ctx.save_for_backward(x, pre, h, w1, w2m)
+        ctx.dtypes = (w1.dtype, b1.dtype, w2.dtype, b2.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pre, h, w1, w2m = ctx.saved_tensors
+        Ch, C = w1.shape[0], w1.shape[1]
+        dy = dy.contiguous()
+        g = pwconv_ex(w2m.t().contiguous(), dy, None, EPI_DGELU, pre)
+        dw2, db2 = pwgrad(dy, h)
+        dT = tapsum_bwd(g)
+        da1, rs = pwgrad(dT, x)                                                    # [9*Ch, C], [9*Ch]
+        dw1 = da1.view(3, 3, Ch, C).permute(2, 3, 0, 1)
+        db1 = rs[4 * Ch:5 * Ch]                                                    # centre tap rows == g itself
+        dx = None
+        if ctx.needs_input_grad[0]:
+            a1t = w1.to(_BF16).permute(1, 2, 3, 0).reshape(C, 9 * Ch).contiguous()  # cols t*Ch + m
+            dx = pwconv_ex(a1t, dT)
+        t = ctx.dtypes
+        return dx, dw1.to(t[0]), db1.to(t[1]), dw2.to(t[2]), db2.to(t[3])
+
+
+def mlp_adapter(x, w1, b1, w2, b2):
+    return _MlpAdapterFn.apply(x, w1, b1, w2, b2)
+
+
+def conv_adapter(x, w1, b1, w2, b2):
+    return _ConvAdapterFn.apply(x, w1, b1, w2, b2)

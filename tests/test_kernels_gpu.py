@@ -376,3 +376,59 @@ def test_pwconv_mfma(device, B, M, K, H, W):
     y2.backward(go.to(device))
     gref = torch.einsum("mk,bmhw->bkhw", w.float().view(M, K), go.float())
     assert (xd.grad.float().cpu() - gref).abs().max() <= gref.abs().max() * 2 ** -7
+
+
+@pytest.mark.parametrize("B,M,N,H,W", [(2, 128, 128, 12, 40), (3, 288, 128, 48, 160), (2, 100, 36, 6, 20),
+                                       (12, 1152, 512, 12, 40), (1, 32, 256, 3, 8)])
+def test_pwgrad_mfma(device, B, M, N, H, W):
+    """Pixel-contraction GEMM (weight gradients) + row sums vs fp32 einsum of the bf16 operands."""
+    from ppeadepth import ops
+    g = _g(M + N)
+    p = torch.randn(B, M, H, W, generator=g).bfloat16()
+    q = torch.randn(B, N, H, W, generator=g).bfloat16()
+    ref = torch.einsum("bmhw,bnhw->mn", p.double(), q.double()).float()
+    rs_ref = p.double().sum((0, 2, 3)).float()
+    c, rs = ops.pwgrad(p.to(device), q.to(device))
+    assert (c.cpu() - ref).abs().max() <= 1e-4 * (B * H * W) ** 0.5 + 1e-5 * ref.abs().max()
+    assert (rs.cpu() - rs_ref).abs().max() <= 1e-4 * (B * H * W) ** 0.5
+    c2, none = ops.pwgrad(p.to(device), q.to(device), want_rowsum=False)
+    assert none is None and torch.equal(c2, c)                     # deterministic
+
+
+def _adapter_ref(kind, x, w1, b1, w2, b2):
+    import torch.nn.functional as F
+    if kind == "conv":
+        h = F.gelu(F.conv2d(x, w1, b1, padding=1))
+    else:
+        h = F.gelu(torch.einsum("mk,bkhw->bmhw", w1, x) + b1.view(1, -1, 1, 1))
+    return torch.einsum("cm,bmhw->bchw", w2, h) + b2.view(1, -1, 1, 1)
+
+
+@pytest.mark.parametrize("kind", ["conv", "mlp"])
+@pytest.mark.parametrize("B,C,H,W", [(2, 128, 12, 40), (2, 256, 6, 20), (1, 128, 48, 160), (3, 512, 4, 8)])
+def test_adapters_mfma(device, kind, B, C, H, W):
+    """Adapter / B_Adapter forward + all gradients on the MFMA kernels vs an fp32 autograd reference
+    evaluated on the same bf16-rounded inputs and parameters."""
+    from ppeadepth import ops
+    Ch = C // 4
+    g = _g(C + H)
+    x = torch.randn(B, C, H, W, generator=g).bfloat16()
+    w1 = (torch.randn(*((Ch, C, 3, 3) if kind == "conv" else (Ch, C)), generator=g) /
+          (C * (9 if kind == "conv" else 1)) ** 0.5).bfloat16()
+    b1 = (0.1 * torch.randn(Ch, generator=g)).bfloat16()
+    w2 = (torch.randn(C, Ch, generator=g) / Ch ** 0.5).bfloat16()
+    b2 = (0.1 * torch.randn(C, generator=g)).bfloat16()
+    go = torch.randn(B, C, H, W, generator=g).bfloat16()
+    leaves = [t.float().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    ref = _adapter_ref(kind, *leaves)
+    ref.backward(go.float())
+    dl = [t.to(device).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    assert ops.adapter_supported(dl[0], Ch)
+    y = (ops.conv_adapter if kind == "conv" else ops.mlp_adapter)(*dl)
+    y.backward(go.to(device))
+    tol = 2 ** -6
+    assert (y.float().cpu() - ref).abs().max() <= tol * ref.abs().max()
+    for name, a, r in zip(("dx", "dw1", "db1", "dw2", "db2"), dl, leaves):
+        assert a.grad.dtype == a.dtype
+        err = (a.grad.float().cpu() - r.grad).abs().max()
+        assert err <= tol * r.grad.abs().max(), (name, float(err), float(r.grad.abs().max()))
