@@ -12,7 +12,8 @@
 //   * block = 4 waves, tile BM x 128 pixels, BK = 32; `v_mfma_f32_16x16x32_bf16`;
 //   * A tile [BM][32] with a 96-byte row stride, B tile XOR-swizzled in 8-byte chunks: both fragment
 //     reads are bank-conflict free (cdna_hip_programming.md 2, T10);
-//   * global -> register prefetch of the next K-tile overlaps the MFMAs of the current one.
+//   * global -> register prefetch of the next K-tile overlaps the MFMAs of the current one; LDS is
+//     double buffered so a K step costs one barrier.
 #include "common.h"
 
 namespace {
@@ -46,9 +47,8 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
     constexpr int A_BYTES = BM * A_STRIDE, B_BYTES = BK * B_STRIDE;
     constexpr int A_CH = (BM * 4 + 255) / 256;  // 16-byte chunks of the A tile per thread
-    __shared__ __attribute__((aligned(16))) uint8_t lds[A_BYTES + B_BYTES];
-    uint8_t* As = lds;
-    uint8_t* Bs = lds + A_BYTES;
+    constexpr int BUF = A_BYTES + B_BYTES;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BUF];      // double buffered: one barrier per K step
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
                                 : make_uint4(0, 0, 0, 0);
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](uint8_t* As) {
+        uint8_t* Bs = As + A_BYTES;
 #pragma unroll
         for (int c = 0; c < A_CH; ++c)
             if (a_row[c] < BM) *reinterpret_cast<uint4*>(As + a_row[c] * A_STRIDE + a_ch[c] * 16) = a_reg[c];
@@ -97,29 +98,31 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
         }
     };
 
-    // fragment addresses
+    // fragment offsets inside a buffer
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
-    const uint8_t* a_frag = As + (wm * TM + li) * A_STRIDE + g * 16;
+    const int a_off = (wm * TM + li) * A_STRIDE + g * 16;
     const int b_rowi = 8 * g + q;
-    const uint8_t* b_frag = Bs + b_rowi * B_STRIDE;
+    const int b_off = A_BYTES + b_rowi * B_STRIDE;
     const int b_s = b_swz(b_rowi);
 
     load_tiles(0);
+    store_tiles(lds);
+    __syncthreads();
+    int cur = 0;
     for (int k0 = 0; k0 < K; k0 += BK) {
-        __syncthreads();                          // previous tile's fragment reads are done
-        store_tiles();
-        __syncthreads();
-        if (k0 + BK < K) load_tiles(k0 + BK);     // prefetch while the MFMAs run
+        const bool more = k0 + BK < K;
+        if (more) load_tiles(k0 + BK);            // in flight while the MFMAs of this step run
+        const uint8_t* buf = lds + cur * BUF;
         bf16x8 af[MT], bfr[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-            af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_frag + i * 16 * A_STRIDE));
+            af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + a_off + i * 16 * A_STRIDE));
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int chunk = (((wn * TN + 16 * j) >> 2) + pp) ^ b_s;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b_frag + (chunk << 3)));
-            const s16x4 hi =
-                __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(b_frag + 4 * B_STRIDE + (chunk << 3)));
+            const uint8_t* bp = buf + b_off + (chunk << 3);
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp + 4 * B_STRIDE));
             typedef __attribute__((ext_vector_type(8))) short s16x8;
             const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             bfr[j] = __builtin_bit_cast(bf16x8, both);
@@ -129,6 +132,9 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if (more) store_tiles(lds + (cur ^ 1) * BUF);   // the other buffer was last read one barrier ago
+        __syncthreads();
+        cur ^= 1;
     }
 
     // epilogue: C layout col = lane & 15 (pixel), row = 4 * (lane >> 4) + r (output channel)

@@ -8,6 +8,9 @@ import torch
 import torch.nn as nn
 
 
+CHANNELS_LAST = True
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -78,6 +81,15 @@ class ResnetEncoder(nn.Module):
     def forward(self, input_image):
         e = self.encoder
         x = (input_image - 0.45) / 0.225
+        if CHANNELS_LAST and x.is_cuda:
+            # MIOpen's implicit-GEMM convolutions are NHWC-native: keep the whole trunk in channels_last so
+            # that no conv pays a layout round trip
+            if not getattr(self, "_channels_last", False):
+                for m in e.modules():
+                    if isinstance(m, nn.Conv2d):
+                        m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+                self._channels_last = True
+            x = x.contiguous(memory_format=torch.channels_last)
         self.features = [e.relu(e.bn1(e.conv1(x)))]
         self.features.append(e.layer1(e.maxpool(self.features[-1])))
         self.features.append(e.layer2(self.features[-1]))

@@ -19,11 +19,12 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("MIOPEN_FIND_MODE", "NORMAL")
 
 UNIT = 8192          # marker id i -> fill of i * UNIT doubles
-N_CAL = 64
+N_CAL = 120
 
 
 def labels_for(model):
     """(module, label) for the modules we segment by; label = path of coarse names."""
+    import torch
     from ppeadepth.networks import replknet_adapter as rka
     out = []
     for name, m in model.named_modules():
@@ -38,6 +39,13 @@ def labels_for(model):
             out.append((m, "adapter"))
         elif isinstance(m, rka.ReparamLargeKernelConv):
             out.append((m, "lk_dw"))
+        elif top in ("depth", "mono_depth") and type(m).__name__ in ("ConvBlock", "Conv3x3") and \
+                name.count(".") <= 2 and not name.endswith(".conv"):
+            out.append((m, "dec_conv:" + top))
+        elif top == "pose_encoder" and type(m).__name__ in ("BasicBlock", "Bottleneck"):
+            out.append((m, "pose_block"))
+        elif top == "pose" and isinstance(m, torch.nn.Conv2d):
+            out.append((m, "pose_dec_conv"))
         elif top in ("encoder", "mono_encoder") and (name.endswith(".stem") or ".transitions." in name and
                                                      name.count(".") == 2):
             out.append((m, "stem/transition"))
@@ -182,7 +190,9 @@ def parse(path, names_path):
         # path: phase / top module / innermost class label
         tops = [s for s in stack if s.split(" ")[0] in ("encoder", "mono_encoder", "depth", "mono_depth",
                                                         "pose_encoder", "pose")]
-        inner = [s for s in stack if s.split(" ")[0] in ("lkblock", "ffn", "adapter", "lk_dw", "stem/transition")]
+        inner = [s for s in stack if s.split(" ")[0] in ("lkblock", "ffn", "adapter", "lk_dw", "stem/transition",
+                                                         "pose_block", "pose_dec_conv")
+                 or s.startswith("dec_conv")]
         phase = stack[0] if stack else "?"
         key = (phase, tops[-1].split(" ")[0] if tops else "(trainer)",
                "/".join(s.split(" ")[0] for s in inner) if inner else "-")
