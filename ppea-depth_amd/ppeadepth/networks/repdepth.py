@@ -23,6 +23,9 @@ from .resnet_encoder import ResnetEncoder
 _ENC_CH = {"b": [128, 256, 512, 1024], "l": [192, 384, 768, 1536]}
 
 
+TWO_STREAMS = True
+
+
 def _g(opt, name, default):
     return getattr(opt, name, default)
 
@@ -127,6 +130,12 @@ class RepDepth(nn.Module):
                   sum(p.numel() for p in m.parameters()))
 
     # repdepth.py:443-509
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = self._side = torch.cuda.Stream(device)
+        return st
+
     def predict_poses(self, inputs):
         outputs = {}
         frames = {f: inputs[("color_aug", f, 0)] for f in self.opt.frame_ids}
@@ -165,7 +174,20 @@ class RepDepth(nn.Module):
         mono_outputs, outputs = {}, {}
         book = self._bn_book if self.training else None
         set_deferred(book)
+        # Teacher branch (mono encoder + decoder) and student branch (poses, matching encoder, cost volume,
+        # multi-frame encoder + decoder) do not depend on each other before the loss: the teacher is enqueued
+        # on a side stream, forked here and joined below.  The step is thousands of small kernels that cannot
+        # fill 256 CUs one at a time; two independent chains (forward and, through autograd's stream
+        # bookkeeping, backward; both captured as parallel branches of the step graph) overlap them.
+        img_aug = inputs[("color_aug", 0, 0)]
+        side = None
+        if TWO_STREAMS and img_aug.is_cuda and self.training and not self.freeze_tp:
+            side = self._side_stream(img_aug.device)
+            side.wait_stream(torch.cuda.current_stream())
         try:
+            if side is not None:
+                with torch.cuda.stream(side):
+                    mono_outputs.update(self.mono_depth(self.mono_encoder(img_aug)))
             if not self.freeze_tp and not self.freeze_pose:
                 pose_pred = self.predict_poses(inputs)
             else:
@@ -190,8 +212,9 @@ class RepDepth(nn.Module):
             relative_poses = relative_poses * (~nopose).to(relative_poses.dtype)[:, None, None, None]
             outputs["augmentation_mask"] = (static | nopose).float().reshape(B, 1, 1, 1)
 
-            img_aug = inputs[("color_aug", 0, 0)]
-            if not self.freeze_tp:
+            if side is not None:
+                pass
+            elif not self.freeze_tp:
                 mono_outputs.update(self.mono_depth(self.mono_encoder(img_aug)))
             else:
                 with torch.no_grad():
@@ -207,6 +230,12 @@ class RepDepth(nn.Module):
             size = [opt.height, opt.width]
             outputs["lowest_cost"] = F.interpolate(lowest_cost.unsqueeze(1), size, mode="nearest")[:, 0]
             outputs["consistency_mask"] = F.interpolate(confidence_mask.unsqueeze(1), size, mode="nearest")[:, 0]
+            if side is not None:
+                main = torch.cuda.current_stream()
+                main.wait_stream(side)
+                for v in mono_outputs.values():          # produced on the side stream, consumed on this one
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(main)
         finally:
             set_deferred(None)
             if book is not None:
