@@ -134,6 +134,8 @@ class RepDepth(nn.Module):
         st = getattr(self, "_side", None)
         if st is None or st.device != device:
             st = self._side = torch.cuda.Stream(device)
+            from . import replknet_adapter
+            replknet_adapter.NO_FORK_ON.add(st.cuda_stream)      # no nested forks (HIP graph capture faults)
         return st
 
     def predict_poses(self, inputs):

@@ -32,6 +32,27 @@ def get_bn(channels):
     return BatchNorm2d(channels, sync=use_sync_bn)
 
 
+ADAPTER_STREAMS = True   # adapter branch of every block on a side stream (parallel branch of the step graph)
+_SIDE = {}
+NO_FORK_ON = set()       # cuda_stream handles on which adapters run inline (already a forked branch)
+
+
+def _forked_adapter(adapter, inp):
+    """Run `adapter(inp)` on a side stream forked from the current one; returns (output, join) where join()
+    must be called on the current stream before the output is consumed."""
+    main = torch.cuda.current_stream()
+    key = (inp.device.index, main.cuda_stream)
+    side = _SIDE.get(key)
+    if side is None:
+        side = _SIDE[key] = torch.cuda.Stream(inp.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = adapter(inp)
+    # No record_stream needed: `inp` outlives the block, and `out` returns to the side stream's pool only
+    # after the consumer on `main` has been enqueued -- the next fork waits for `main` before reusing it.
+    return out, lambda: main.wait_stream(side)
+
+
 class DropPath(nn.Module):
     """timm DropPath (stochastic depth per sample, scale_by_keep) with an injectable RNG."""
 
@@ -297,9 +318,17 @@ class ConvFFN(nn.Module):
     def forward(self, x):
         if FUSE_BN and self.training and x.is_cuda:
             out = fused_bn_act(x, self.preffn_bn)
-            adpt = self.mlp_adapter(out) if self.test_id >= 0 else None
+            adpt, join = None, None
+            if self.test_id >= 0:
+                if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
+                    adpt, join = _forked_adapter(self.mlp_adapter, out)
+                else:
+                    adpt = self.mlp_adapter(out)
             h = fused_bn_act(self.pw1.conv(out), self.pw1.bn, act=ops.ACT_GELU)
-            return fused_bn_act(self.pw2.conv(h), self.pw2.bn, mask=_drop_mask(self.drop_path, x), r1=x, r2=adpt,
+            z = self.pw2.conv(h)
+            if join is not None:
+                join()
+            return fused_bn_act(z, self.pw2.bn, mask=_drop_mask(self.drop_path, x), r1=x, r2=adpt,
                                 r2_scale=self.gamma)
         out = self.preffn_bn(x)
         adpt = self.mlp_adapter(out) if self.test_id >= 0 else None
@@ -328,9 +357,17 @@ class RepLKBlock(nn.Module):
     def forward(self, x):
         if FUSE_BN and self.training and x.is_cuda and hasattr(self.large_kernel, "small_conv"):
             out = fused_bn_act(x, self.prelkb_bn)
-            adpt = self.adapter(out) if self.test_id >= 0 else None
+            adpt, join = None, None
+            if self.test_id >= 0:
+                if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
+                    adpt, join = _forked_adapter(self.adapter, out)
+                else:
+                    adpt = self.adapter(out)
             t = self.large_kernel.forward_act(self.pw1(out), ops.ACT_RELU)
-            return fused_bn_act(self.pw2.conv(t), self.pw2.bn, mask=_drop_mask(self.drop_path, x), r1=x, r2=adpt,
+            z = self.pw2.conv(t)
+            if join is not None:
+                join()
+            return fused_bn_act(z, self.pw2.bn, mask=_drop_mask(self.drop_path, x), r1=x, r2=adpt,
                                 r2_scale=self.gamma)
         out = self.prelkb_bn(x)
         adpt = self.adapter(out) if self.test_id >= 0 else None
