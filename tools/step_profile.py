@@ -49,6 +49,17 @@ def main():
     print(f"steps {steps}: wall {wall:.1f} ms/step, kernel time {tot/1e6/steps:.1f} ms/step, {len(sel)//steps} launches/step")
     for k, (t, c) in sorted(agg.items(), key=lambda x: -x[1][0]):
         print(f"  {k:30s} {t/1e6/steps:8.2f} ms/step {100*t/tot:5.1f}%  {c//steps:6d} launches/step")
+    # concurrency: share of the step's wall time with 0 / 1 / 2 / 3+ kernels in flight (parallel graph branches)
+    ev = []
+    for st, en, _ in sel:
+        ev.append((st, 1)); ev.append((en, -1))
+    ev.sort()
+    hist, depth, last = collections.defaultdict(float), 0, ev[0][0]
+    for t, d in ev:
+        hist[min(depth, 3)] += t - last
+        depth += d; last = t
+    span = sum(hist.values())
+    print("kernels in flight: " + "  ".join(f"{k if k < 3 else '3+'}: {100 * v / span:.1f}%" for k, v in sorted(hist.items())))
     print("top kernels:")
     for n, (t, c) in sorted(per.items(), key=lambda x: -x[1][0])[:30]:
         print(f"  {t/1e6/steps:7.2f} ms/step {c//steps:5d}/step avg {t/c/1e3:8.1f} us  {n[:110]}")
