@@ -86,6 +86,10 @@ def main():
     from oracle import synth
 
     rank, local_rank, world = pdist.init_distributed()
+    if os.environ.get("PPEA_STREAMS") is not None:       # parallel graph branches on/off (default on)
+        on = os.environ["PPEA_STREAMS"] == "1"
+        networks.repdepth.TWO_STREAMS = on
+        networks.replknet_adapter.ADAPTER_STREAMS = on
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
@@ -99,6 +103,9 @@ def main():
     synth.fill_state_dict(model)                 # deterministic random-init weights (no checkpoints offline)
     model.to(device).train()
     pdist.broadcast_module(model)
+    if pdist.collectives_on():
+        from ppeadepth import batchnorm
+        batchnorm.assign_groups(model)           # teacher / student SyncBN exchanges on separate communicators
     amp = torch.bfloat16 if args.dtype == "bf16" else None
     trainer = Trainer(opt, model, device, amp_dtype=amp)
     engine = pdist.TrainEngine(trainer, bf16_params=(args.dtype == "bf16"))
@@ -121,16 +128,32 @@ def main():
     engine.step(dict(inputs))
     barrier()
     events, ops.PROFILE_DWCONV = ops.PROFILE_DWCONV, None
-    # Several ranks: the captured graph would contain several hundred RCCL collectives (SyncBN statistics)
-    # plus the gradient all-reduce on a side stream; that path cannot be exercised on the one-GPU
-    # development box, so it is opt-in (PPEA_MULTI_GRAPH=1) and the default for N > 1 is eager launches.
-    use_graph = (not args.eager) and (world == 1 or os.environ.get("PPEA_MULTI_GRAPH") == "1")
+    # Several ranks: the captured step also holds the RCCL calls (SyncBN all-gathers / all-reduces on per-branch
+    # communicators, the gradient all-reduce on a side stream).  Capture is attempted on every rank; if any
+    # rank fails, all fall back to eager launches (PPEA_MULTI_GRAPH=0 skips the attempt).
+    multi = pdist.collectives_on()
+    use_graph = (not args.eager) and (not multi or os.environ.get("PPEA_MULTI_GRAPH", "1") == "1")
+    if use_graph:
+        ok = 1
+        try:
+            engine.capture(inputs, warmup=1)
+        except Exception as ex:                  # noqa: BLE001 -- any capture failure means eager
+            ok = 0
+            print(f"[bench] rank {rank}: graph capture failed ({type(ex).__name__}: {ex}); eager fallback",
+                  file=sys.stderr, flush=True)
+        if multi:
+            flag = torch.tensor([ok], device=device, dtype=torch.int32)
+            torch.cuda.synchronize()
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag)
+        if not ok:
+            engine.graph = None
+            use_graph = False
     args.eager = not use_graph
     if use_graph:
-        engine.capture(inputs, warmup=1)
         for _ in range(2):
             engine.step(inputs)
-        barrier()
+    barrier()
     t0 = time.time()
     for _ in range(args.steps):
         _, losses = engine.step(dict(inputs) if args.eager else inputs)
@@ -197,7 +220,7 @@ def main():
             except Exception as ex:          # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

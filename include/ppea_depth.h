@@ -139,6 +139,12 @@ int ppea_bn_stats_bf16(const void* z, float* partial, int N, int C, int HW, void
 int ppea_bn_finalize_f32(const float* partial, int N, int C, int HW, float eps, float momentum,
                          float* mean, float* var, float* invstd, float* running_mean,
                          float* running_var, void* stream);
+/* SyncBatchNorm across ranks (one packed all-gather per BN forward, trainer.py:215-222 + get_bn rka.py:176-180):
+ * local statistics in wire layout packed[2C+1] = mean[C] | biased var[C] | count, and the Chan combine of the
+ * gathered [world][2C+1] table into mean / invstd (running statistics updated unless running_mean is NULL). */
+int ppea_bn_finalize_packed_f32(const float* partial, int N, int C, int HW, float* packed, void* stream);
+int ppea_bn_sync_combine_f32(const float* gathered, int world, int C, float eps, float momentum, float* mean,
+                             float* invstd, float* running_mean, float* running_var, void* stream);
 int ppea_bn_apply_f32(const void* z1, const void* z2, const float* const* stats, const float* mask,
                       const void* r1, const void* r2, float r2_scale, void* y, int act,
                       int N, int C, int HW, void* stream);

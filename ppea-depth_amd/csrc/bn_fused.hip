@@ -116,6 +116,53 @@ __global__ void bn_finalize(const float* __restrict__ partial, int N, int C, int
     }
 }
 
+// SyncBN (several ranks): local statistics in the layout that goes on the wire, packed[2C+1] = mean[C] |
+// biased var[C] | count, and the Chan combine of the gathered [world][2C+1] table (+ running statistics).
+__global__ void bn_finalize_packed(const float* __restrict__ partial, int N, int C, int HW,
+                                   float* __restrict__ packed) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) packed[2 * C] = (float)N * (float)HW;
+    if (c >= C) return;
+    const float* p = partial + (long)c * N * 2;
+    float mean = 0.f;
+    for (int n = 0; n < N; ++n) mean += p[2 * n];
+    mean /= (float)N;
+    float m2 = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float d = p[2 * n] - mean;
+        m2 += p[2 * n + 1] + (float)HW * d * d;
+    }
+    packed[c] = mean;
+    packed[C + c] = m2 / ((float)N * (float)HW);
+}
+
+__global__ void bn_sync_combine(const float* __restrict__ gathered, int world, int C, float eps, float momentum,
+                                float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int pitch = 2 * C + 1;
+    float total = 0.f, mean = 0.f;
+    for (int r = 0; r < world; ++r) {
+        const float cnt = gathered[(long)r * pitch + 2 * C];
+        total += cnt;
+        mean += cnt * gathered[(long)r * pitch + c];
+    }
+    mean /= total;
+    float m2 = 0.f;
+    for (int r = 0; r < world; ++r) {
+        const float cnt = gathered[(long)r * pitch + 2 * C];
+        const float d = gathered[(long)r * pitch + c] - mean;
+        m2 += cnt * (gathered[(long)r * pitch + C + c] + d * d);
+    }
+    mean_out[c] = mean;
+    invstd_out[c] = rsqrtf(m2 / total + eps);
+    if (running_mean != nullptr) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / fmaxf(total - 1.f, 1.f));
+    }
+}
+
 struct Branch {
     const float* mean;
     const float* invstd;
@@ -521,6 +568,19 @@ int ppea_bn_finalize_f32(const float* partial, int N, int C, int HW, float eps, 
     if (N <= 0 || C <= 0 || HW <= 0) return PPEA_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(bn_finalize, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, N, C, HW, eps,
                        momentum, mean, var, invstd, running_mean, running_var);
+    return launch_status();
+}
+int ppea_bn_finalize_packed_f32(const float* partial, int N, int C, int HW, float* packed, void* stream) {
+    if (N <= 0 || C <= 0 || HW <= 0) return PPEA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_finalize_packed, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, N, C, HW,
+                       packed);
+    return launch_status();
+}
+int ppea_bn_sync_combine_f32(const float* gathered, int world, int C, float eps, float momentum, float* mean,
+                             float* invstd, float* running_mean, float* running_var, void* stream) {
+    if (world <= 0 || C <= 0) return PPEA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_sync_combine, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, gathered, world, C, eps,
+                       momentum, mean, invstd, running_mean, running_var);
     return launch_status();
 }
 int ppea_bn_apply_f32(const void* z1, const void* z2, const float* const* stats, const float* mask, const void* r1,

@@ -75,6 +75,11 @@ def set_deferred(d):
     _ACTIVE_DEFERRED = d
 
 
+def _collectives_on():
+    from .dist import collectives_on
+    return collectives_on()
+
+
 class _SyncBNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, group):
@@ -114,27 +119,40 @@ def _global_stats(bn, z):
     launches (running stats updated in the second).  Several ranks (sync BN): local stats -> one packed
     all-gather -> Chan combine; running stats updated with the global statistics."""
     from . import ops
-    multi = bn.sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    multi = bn.sync and _collectives_on()
     cnt = z.numel() // z.shape[1]
     if not multi:
         mean, _var, invstd = ops.bn_batch_stats(z, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
         return mean, invstd, float(cnt), None
-    mean_l, var_l, _ = ops.bn_batch_stats(z, bn.eps, bn.momentum, None, None)
-    C = mean_l.shape[0]
-    world = dist.get_world_size()
-    packed = torch.cat([mean_l, var_l, mean_l.new_full((1,), float(cnt))])
-    gathered = torch.empty(world, 2 * C + 1, device=z.device, dtype=packed.dtype)
-    dist.all_gather(list(gathered.unbind(0)), packed)         # list form: works on RCCL and on gloo
-    means, vars_, counts = gathered[:, :C], gathered[:, C:2 * C], gathered[:, 2 * C:2 * C + 1]
-    total = counts.sum()
-    mean = (means * counts).sum(0) / total
-    m2 = ((vars_ + (means - mean) ** 2) * counts).sum(0)
-    var = m2 / total
-    invstd = torch.rsqrt(var + bn.eps)
-    with torch.no_grad():
-        bn.running_mean.lerp_(mean, bn.momentum)
-        bn.running_var.lerp_(m2 / (total - 1), bn.momentum)
-    return mean, invstd, float(cnt * world), (None,)
+    # several ranks: stats + packed finalize (2 launches) -> ONE all-gather -> combine (1 launch)
+    group = getattr(bn, "group", None)
+    world = dist.get_world_size(group)
+    packed = ops.bn_local_stats_packed(z)
+    gathered = torch.empty(world, packed.numel(), device=z.device, dtype=packed.dtype)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(gathered, packed, group=group)
+    else:
+        dist.all_gather(list(gathered.unbind(0)), packed, group=group)     # gloo has no tensor form
+    mean, invstd = ops.bn_sync_combine(gathered, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+    return mean, invstd, float(cnt * world), (group,)
+
+
+def assign_groups(model):
+    """One process group per concurrently running branch: ProcessGroupNCCL runs a group's collectives in order
+    on one internal stream, so the teacher's and the student's SyncBN exchanges must not share a group or the
+    two branches of the step serialise on it.  Call on every rank, after init_process_group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
+        return
+    groups = {}
+    for top in ("mono_encoder", "encoder"):
+        sub = getattr(model, top, None)
+        if sub is None:
+            continue
+        groups[top] = dist.new_group()
+        for m in sub.modules():
+            if isinstance(m, BatchNorm2d):
+                m.group = groups[top]
+    return groups
 
 
 def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None, r2_scale=1.0):
@@ -185,10 +203,11 @@ class BatchNorm2d(nn.Module):
             return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
                                 False, self.momentum, self.eps)
         count = x.numel() // x.shape[1]
-        multi = self.sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        multi = self.sync and _collectives_on()
         if multi:
             out, mean, invstd = _SyncBNFn.apply(x, self.weight, self.bias, self.running_mean,
-                                                self.running_var, self.eps, self.momentum, None)
+                                                self.running_var, self.eps, self.momentum,
+                                                getattr(self, "group", None))
             count = count * dist.get_world_size()
         else:
             out, mean, invstd = torch.native_batch_norm(x, self.weight, self.bias, self.running_mean,

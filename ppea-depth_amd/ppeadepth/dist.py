@@ -18,12 +18,22 @@ import torch
 import torch.distributed as dist
 
 
+# Test hook: run every collective of the multi-rank path (SyncBN statistics, gradient all-reduce) through the
+# process group even when it has a single rank -- exercises ProcessGroupNCCL/RCCL plumbing (incl. graph
+# capture) on a one-GPU box.
+FORCE_COLLECTIVES = os.environ.get("PPEA_FORCE_COLLECTIVES") == "1"
+
+
+def collectives_on():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
 def init_distributed(backend=None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun contract)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE_COLLECTIVES) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -95,7 +105,7 @@ class FlatGrads:
     def all_reduce_mean(self):
         """Mean over ranks (DDP semantics) in a few large chunks on a side stream."""
         w = world_size()
-        if w == 1:
+        if not collectives_on():
             return
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
@@ -132,7 +142,7 @@ class TrainEngine:
         self.opt_params = [self.masters.get(id(p), p) for p in self.params] if self.masters else self.params
         self._lo = [p for p in self.params if self.masters and id(p) in self.masters]
         self._hi = [self.masters[id(p)] for p in self._lo]
-        self.flat = FlatGrads(self.opt_params, n_chunks) if world_size() > 1 else None
+        self.flat = FlatGrads(self.opt_params, n_chunks) if collectives_on() else None
         if self.flat is None and self._lo:
             self._hi_grads = [torch.zeros_like(m) for m in self._hi]
             for m, g in zip(self._hi, self._hi_grads):

@@ -375,6 +375,27 @@ def bn_batch_stats(z, eps, momentum, running_mean=None, running_var=None):
     return out[0], out[1], out[2]
 
 
+def bn_local_stats_packed(z):
+    """SyncBN wire format of the local statistics: [mean(C) | biased var(C) | count] fp32."""
+    z = z.contiguous()
+    N, C = z.shape[0], z.shape[1]
+    HW = z.numel() // (N * C)
+    partial = torch.empty(C * N * 2, device=z.device, dtype=_F32)
+    packed = torch.empty(2 * C + 1, device=z.device, dtype=_F32)
+    call(f"ppea_bn_stats_{_suffix(z)}", ptr(z), ptr(partial), N, C, HW, stream_ptr())
+    call("ppea_bn_finalize_packed_f32", ptr(partial), N, C, HW, ptr(packed), stream_ptr())
+    return packed
+
+
+def bn_sync_combine(gathered, eps, momentum, running_mean=None, running_var=None):
+    """gathered [world, 2C+1] -> (mean, invstd) of the global batch; running statistics updated in the launch."""
+    world, C = gathered.shape[0], (gathered.shape[1] - 1) // 2
+    out = torch.empty(2, C, device=gathered.device, dtype=_F32)
+    call("ppea_bn_sync_combine_f32", ptr(gathered, _F32), world, C, float(eps), float(momentum), ptr(out[0]),
+         ptr(out[1]), ptr(running_mean), ptr(running_var), stream_ptr())
+    return out[0], out[1]
+
+
 class _BnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z1, g1, b1, mean1, invstd1, z2, g2, b2, mean2, invstd2, mask, r1, r2, r2_scale, act,

@@ -50,7 +50,8 @@ class DepthBins:
     def compute(self):
         mn, mx = self.min_depth.float(), self.max_depth.float()
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        from .dist import collectives_on
+        if collectives_on():
             pack = torch.stack([-mn.reshape(()), mx.reshape(())])
             dist.all_reduce(pack, op=dist.ReduceOp.MAX)          # min via max of the negation
             mn, mx = -pack[0], pack[1]

@@ -71,7 +71,7 @@ def test_two_ranks_match_global_batch(device):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
