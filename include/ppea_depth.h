@@ -98,7 +98,8 @@ int ppea_pwconv_bf16(const void* A, const void* X, const float* bias, void* Y, i
  *
  *   ppea_pwconv_ex_bf16   the GEMM above with an epilogue. epi 0: Y = A X + bias.  epi 1: Y = pre-activation,
  *                         Y2 = GELU(pre).  epi 2: Y = (A X) * GELU'(aux)  (aux, Y, Y2: [B][M][HW] bf16).
- *                         bias: fp32, or bf16 when bias_bf16 != 0.
+ *                         bias: fp32, or bf16 when bias_bf16 != 0.  a_transposed != 0: the matrix is passed as
+ *                         At [K][M] (M % 8 == 0), so a data gradient consumes the forward weight unchanged.
  *   ppea_pwgrad_bf16      weight gradients: out[m*N + n] = sum_{b,p} P[b][m][p] Q[b][n][p] (fp32), followed by
  *                         the row sums of P (bias gradient) at out[M*N + m] when want_rowsum != 0.
  *                         P [B][M][HW], Q [B][N][HW] bf16, HW % 8 == 0.  `workspace`: device scratch of
@@ -109,10 +110,15 @@ int ppea_pwconv_bf16(const void* A, const void* X, const float* bias, void* Y, i
  *   ppea_tapsum_bwd_bf16  its adjoint: dT[b][t*Ch+m][y][x] = g[b][m][y-ky+1][x-kx+1].
  * ---------------------------------------------------------------------------------------- */
 int ppea_pwconv_ex_bf16(const void* A, const void* X, const void* bias, int bias_bf16, int epi, const void* aux,
-                        void* Y, void* Y2, int B, int M, int K, int HW, void* stream);
+                        void* Y, void* Y2, int B, int M, int K, int HW, int a_transposed, void* stream);
 long ppea_pwgrad_workspace_bytes(int B, int M, int N, int HW);
 int ppea_pwgrad_bf16(const void* P, const void* Q, float* out, void* workspace, int B, int M, int N, int HW,
                      int want_rowsum, void* stream);
+/* ppea_pwgrad_ex_bf16: same GEMM, results written straight into the parameter gradients: out_w fp32 or bf16
+ * (out_w_bf16), [M][N] for taps = 1 or, for the tap-major 3x3 form (taps = 9, rows t*Ch + m), nn.Conv2d layout
+ * [Ch][N][3][3]; out_b (may be NULL) = row sums of rows [b_row0, b_row0 + b_rows). */
+int ppea_pwgrad_ex_bf16(const void* P, const void* Q, void* workspace, int B, int M, int N, int HW, void* out_w,
+                        int out_w_bf16, int taps, void* out_b, int out_b_bf16, int b_row0, int b_rows, void* stream);
 int ppea_tapsum_fwd_bf16(const void* T, const void* bias, int bias_bf16, void* pre, void* h, int B, int Ch, int H,
                          int W, void* stream);
 int ppea_tapsum_bwd_bf16(const void* g, void* dT, int B, int Ch, int H, int W, void* stream);

@@ -38,15 +38,18 @@ __device__ __forceinline__ float dgelu_f(float x) {
 
 // EPI 0: Y = acc + bias.   EPI 1: Y = pre = acc + bias, Y2 = GELU(pre) (pre rounded to bf16 first, like an
 // autocast nn.GELU on the stored tensor).   EPI 2: Y = acc * GELU'(aux[n][m][p]) (data gradient through GELU).
-template <int BM, int WM, int WN, int EPI>
+// TA: the matrix is given transposed, At [K][M] (m contiguous) -- its tile is staged like the X tile and the A
+// fragments come out of the transposing LDS read as well, so a data gradient uses the forward weight as is.
+template <int BM, int WM, int WN, int EPI, bool TA>
 __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ X,
                                                      const void* __restrict__ bias, int bias_bf16,
                                                      const uint16_t* __restrict__ aux, uint16_t* __restrict__ Y,
                                                      uint16_t* __restrict__ Y2, int M, int K, int HW) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
-    constexpr int A_BYTES = BM * A_STRIDE, B_BYTES = BK * B_STRIDE;
+    constexpr int A_BYTES = TA ? BK * B_STRIDE : BM * A_STRIDE, B_BYTES = BK * B_STRIDE;
     constexpr int A_CH = (BM * 4 + 255) / 256;  // 16-byte chunks of the A tile per thread
+    constexpr int A_CPR = TA ? BM / 8 : 4;      // chunks per staged row: [32 k][BM m] or [BM m][32 k]
     constexpr int BUF = A_BYTES + B_BYTES;
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BUF];      // double buffered: one barrier per K step
 
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
     // per-thread staging coordinates
     int a_row[A_CH], a_ch[A_CH];
 #pragma unroll
-    for (int c = 0; c < A_CH; ++c) { const int idx = tid + c * 256; a_row[c] = idx >> 2; a_ch[c] = idx & 3; }
+    for (int c = 0; c < A_CH; ++c) { const int idx = tid + c * 256; a_row[c] = idx / A_CPR; a_ch[c] = idx % A_CPR; }
     int b_row[2], b_c16[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) { const int idx = tid + c * 256; b_row[c] = idx >> 4; b_c16[c] = idx & 15; }
@@ -73,9 +76,15 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int c = 0; c < A_CH; ++c) {
-            const int m = m0 + a_row[c];
-            a_reg[c] = (m < M && a_row[c] < BM) ? *reinterpret_cast<const uint4*>(A + (long)m * K + k0 + a_ch[c] * 8)
-                                                : make_uint4(0, 0, 0, 0);
+            if constexpr (TA) {
+                const int m = m0 + a_ch[c] * 8;
+                a_reg[c] = (m < M && a_row[c] < BK) ? *reinterpret_cast<const uint4*>(A + (long)(k0 + a_row[c]) * M + m)
+                                                    : make_uint4(0, 0, 0, 0);
+            } else {
+                const int m = m0 + a_row[c];
+                a_reg[c] = (m < M && a_row[c] < BM)
+                               ? *reinterpret_cast<const uint4*>(A + (long)m * K + k0 + a_ch[c] * 8) : make_uint4(0, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -87,8 +96,18 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
     auto store_tiles = [&](uint8_t* As) {
         uint8_t* Bs = As + A_BYTES;
 #pragma unroll
-        for (int c = 0; c < A_CH; ++c)
-            if (a_row[c] < BM) *reinterpret_cast<uint4*>(As + a_row[c] * A_STRIDE + a_ch[c] * 16) = a_reg[c];
+        for (int c = 0; c < A_CH; ++c) {
+            if constexpr (TA) {
+                if (a_row[c] < BK) {
+                    const int s = b_swz(a_row[c]);
+                    uint8_t* rowp = As + a_row[c] * B_STRIDE;
+                    *reinterpret_cast<uint2*>(rowp + (((2 * a_ch[c]) ^ s) << 3)) = make_uint2(a_reg[c].x, a_reg[c].y);
+                    *reinterpret_cast<uint2*>(rowp + (((2 * a_ch[c] + 1) ^ s) << 3)) = make_uint2(a_reg[c].z, a_reg[c].w);
+                }
+            } else {
+                if (a_row[c] < BM) *reinterpret_cast<uint4*>(As + a_row[c] * A_STRIDE + a_ch[c] * 16) = a_reg[c];
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int s = b_swz(b_row[c]);
@@ -100,8 +119,8 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
 
     // fragment offsets inside a buffer
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
-    const int a_off = (wm * TM + li) * A_STRIDE + g * 16;
     const int b_rowi = 8 * g + q;
+    const int a_off = TA ? b_rowi * B_STRIDE : (wm * TM + li) * A_STRIDE + g * 16;
     const int b_off = A_BYTES + b_rowi * B_STRIDE;
     const int b_s = b_swz(b_rowi);
 
@@ -115,8 +134,19 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
         const uint8_t* buf = lds + cur * BUF;
         bf16x8 af[MT], bfr[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-            af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + a_off + i * 16 * A_STRIDE));
+        for (int i = 0; i < MT; ++i) {
+            if constexpr (TA) {
+                const int chunk = (((wm * TM + 16 * i) >> 2) + pp) ^ b_swz(b_rowi);
+                const uint8_t* ap = buf + a_off + (chunk << 3);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap + 4 * B_STRIDE));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                af[i] = __builtin_bit_cast(bf16x8, both);
+            } else {
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + a_off + i * 16 * A_STRIDE));
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int chunk = (((wn * TN + 16 * j) >> 2) + pp) ^ b_s;
@@ -165,13 +195,13 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
         }
 }
 
-template <int EPI>
+template <int EPI, bool TA>
 int launch_pw(const void* A, const void* X, const void* bias, int bias_bf16, const void* aux, void* Y, void* Y2, int B,
               int M, int K, int HW, hipStream_t st) {
     const int nb = (HW + BN - 1) / BN;
     const long blocks128 = (long)nb * ((M + 127) / 128) * B;
 #define PW_LAUNCH(BM_, WM_, WN_)                                                                                  \
-    hipLaunchKernelGGL((pwconv_kernel<BM_, WM_, WN_, EPI>), dim3(nb, (M + BM_ - 1) / BM_, B), dim3(256), 0, st, \
+    hipLaunchKernelGGL((pwconv_kernel<BM_, WM_, WN_, EPI, TA>), dim3(nb, (M + BM_ - 1) / BM_, B), dim3(256), 0, st, \
                        (const uint16_t*)A, (const uint16_t*)X, bias, bias_bf16, (const uint16_t*)aux, (uint16_t*)Y, \
                        (uint16_t*)Y2, M, K, HW)
     if (M >= 128 && blocks128 >= 512) PW_LAUNCH(128, 2, 2);
@@ -191,21 +221,32 @@ int ppea_pwconv_bf16(const void* A, const void* X, const float* bias, void* Y, i
                      void* stream) {
     if (B <= 0 || M <= 0 || K <= 0 || HW <= 0 || (K % BK) != 0 || (HW % 8) != 0 || B > 65535)
         return PPEA_ERR_UNSUPPORTED;
-    return launch_pw<0>(A, X, bias, 0, nullptr, Y, nullptr, B, M, K, HW, (hipStream_t)stream);
+    return launch_pw<0, false>(A, X, bias, 0, nullptr, Y, nullptr, B, M, K, HW, (hipStream_t)stream);
 }
 
 // Same GEMM with an epilogue (adapters, replknet_adapter.py:20-109): epi 0 plain; epi 1 writes the
 // pre-activation to Y and GELU(pre) to Y2; epi 2 multiplies by GELU'(aux) (aux, Y: [B][M][HW] bf16).
-// `bias` is fp32 or, with bias_bf16 != 0, bf16.
+// `bias` is fp32 or, with bias_bf16 != 0, bf16.  a_transposed != 0: A is given as At [K][M] (M % 8 == 0).
 int ppea_pwconv_ex_bf16(const void* A, const void* X, const void* bias, int bias_bf16, int epi, const void* aux,
-                        void* Y, void* Y2, int B, int M, int K, int HW, void* stream) {
+                        void* Y, void* Y2, int B, int M, int K, int HW, int a_transposed, void* stream) {
     if (B <= 0 || M <= 0 || K <= 0 || HW <= 0 || (K % BK) != 0 || (HW % 8) != 0 || B > 65535)
         return PPEA_ERR_UNSUPPORTED;
+    if (a_transposed && (M % 8) != 0) return PPEA_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    switch (epi) {
-        case 0: return launch_pw<0>(A, X, bias, bias_bf16, nullptr, Y, nullptr, B, M, K, HW, st);
-        case 1: if (!Y2) return PPEA_ERR_ARG; return launch_pw<1>(A, X, bias, bias_bf16, nullptr, Y, Y2, B, M, K, HW, st);
-        case 2: if (!aux) return PPEA_ERR_ARG; return launch_pw<2>(A, X, nullptr, 0, aux, Y, nullptr, B, M, K, HW, st);
+    if (epi == 1 && !Y2) return PPEA_ERR_ARG;
+    if (epi == 2 && !aux) return PPEA_ERR_ARG;
+    if (a_transposed) {
+        switch (epi) {
+            case 0: return launch_pw<0, true>(A, X, bias, bias_bf16, nullptr, Y, nullptr, B, M, K, HW, st);
+            case 1: return launch_pw<1, true>(A, X, bias, bias_bf16, nullptr, Y, Y2, B, M, K, HW, st);
+            case 2: return launch_pw<2, true>(A, X, nullptr, 0, aux, Y, nullptr, B, M, K, HW, st);
+        }
+    } else {
+        switch (epi) {
+            case 0: return launch_pw<0, false>(A, X, bias, bias_bf16, nullptr, Y, nullptr, B, M, K, HW, st);
+            case 1: return launch_pw<1, false>(A, X, bias, bias_bf16, nullptr, Y, Y2, B, M, K, HW, st);
+            case 2: return launch_pw<2, false>(A, X, nullptr, 0, aux, Y, nullptr, B, M, K, HW, st);
+        }
     }
     return PPEA_ERR_ARG;
 }

@@ -147,6 +147,44 @@ __global__ __launch_bounds__(256) void pwgrad_reduce_kernel(const float* __restr
     }
 }
 
+// Same reduction, written straight into the parameter gradients: weights as fp32 or bf16, either [M][N] or,
+// for the tap-major 3x3 form (taps = 9, M = 9 * Ch rows t * Ch + m), in nn.Conv2d layout [Ch][N][3][3];
+// bias = row sums of rows [b_row0, b_row0 + b_rows).
+__global__ __launch_bounds__(256) void pwgrad_reduce_ex_kernel(const float* __restrict__ ws, long pitch, int S, int M,
+                                                               int N, int taps, void* __restrict__ out_w,
+                                                               int w_bf16, void* __restrict__ out_b, int b_bf16,
+                                                               int b_row0, int b_rows) {
+    __shared__ float part[8][33];
+    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+    const long len = (long)M * N + M;
+    const long i = (long)blockIdx.x * 32 + x;
+    float v = 0.f;
+    if (i < len)
+        for (int s = y; s < S; s += 8) v += ws[(long)s * pitch + i];
+    part[y][x] = v;
+    __syncthreads();
+    if (y != 0 || i >= len) return;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += part[k][x];
+    if (i < (long)M * N) {
+        const int m = (int)(i / N), n = (int)(i - (long)m * N);
+        long o = i;
+        if (taps > 1) {
+            const int Ch = M / taps, tp = m / Ch, mo = m - tp * Ch;
+            o = ((long)mo * N + n) * taps + tp;
+        }
+        if (w_bf16) reinterpret_cast<uint16_t*>(out_w)[o] = __builtin_bit_cast(uint16_t, (__bf16)t);
+        else reinterpret_cast<float*>(out_w)[o] = t;
+    } else if (out_b != nullptr) {
+        const int r = (int)(i - (long)M * N) - b_row0;
+        if (r >= 0 && r < b_rows) {
+            if (b_bf16) reinterpret_cast<uint16_t*>(out_b)[r] = __builtin_bit_cast(uint16_t, (__bf16)t);
+            else reinterpret_cast<float*>(out_b)[r] = t;
+        }
+    }
+}
+
 void plan(int B, int M, int N, int HW, int& spi, int& total, int& sps, int& S) {
     spi = (HW + TK - 1) / TK;
     total = B * spi;
@@ -184,6 +222,27 @@ int ppea_pwgrad_bf16(const void* P, const void* Q, float* out, void* workspace, 
     const long len = (long)M * N + (want_rowsum ? M : 0), pitch = (long)M * N + M;
     hipLaunchKernelGGL(pwgrad_reduce_kernel, dim3((unsigned)((len + 31) / 32)), dim3(256), 0, st,
                        (const float*)workspace, out, len, pitch, S);
+    return launch_status();
+}
+
+// As ppea_pwgrad_bf16, results written straight into the parameter gradients (see pwgrad_reduce_ex_kernel).
+int ppea_pwgrad_ex_bf16(const void* P, const void* Q, void* workspace, int B, int M, int N, int HW, void* out_w,
+                        int out_w_bf16, int taps, void* out_b, int out_b_bf16, int b_row0, int b_rows, void* stream) {
+    if (B <= 0 || M <= 0 || N <= 0 || HW <= 0 || (HW % 8) != 0 || taps < 1 || (M % taps) != 0)
+        return PPEA_ERR_UNSUPPORTED;
+    if (out_w == nullptr || (out_b != nullptr && (b_row0 < 0 || b_row0 + b_rows > M))) return PPEA_ERR_ARG;
+    int spi, total, sps, S;
+    plan(B, M, N, HW, spi, total, sps, S);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(S, (M + TM - 1) / TM, (N + TN - 1) / TN);
+    if (grid.y > 65535 || grid.z > 65535) return PPEA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pwgrad_kernel, grid, dim3(256), 0, st, (const uint16_t*)P, (const uint16_t*)Q,
+                       (float*)workspace, M, N, HW, spi, total, sps, out_b != nullptr ? 1 : 0);
+    const long pitch = (long)M * N + M;
+    const long len = out_b != nullptr ? pitch : (long)M * N;
+    hipLaunchKernelGGL(pwgrad_reduce_ex_kernel, dim3((unsigned)((len + 31) / 32)), dim3(256), 0, st,
+                       (const float*)workspace, pitch, S, M, N, taps, out_w, out_w_bf16, out_b, out_b_bf16, b_row0,
+                       b_rows);
     return launch_status();
 }
 

@@ -33,9 +33,10 @@ SIGNATURES = {
     "ppea_dwconv_lk_fwd_bf16p": [_vp] * 5 + [_i] * 6 + [_vp],
     "ppea_dwconv_lk_bwd_data_bf16p": [_vp] * 5 + [_i] * 6 + [_vp],
     "ppea_pwconv_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "ppea_pwconv_ex_bf16": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_pwconv_ex_bf16": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ppea_pwgrad_workspace_bytes": [_i, _i, _i, _i],
     "ppea_pwgrad_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ppea_pwgrad_ex_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "ppea_tapsum_fwd_bf16": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_tapsum_bwd_bf16": [_vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_bn_stats_f32": [_vp, _vp, _i, _i, _i, _vp],

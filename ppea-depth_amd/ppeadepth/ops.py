@@ -585,16 +585,16 @@ def _bias_arg(b):
     return ptr(b, _F32), 0
 
 
-def pwconv_ex(a_mat, x, bias=None, epi=EPI_NONE, aux=None):
-    """A [M,K] bf16 applied over the channel axis of x [B,K,H,W] bf16 with an epilogue:
-    EPI_NONE -> y;  EPI_GELU -> (pre, gelu(pre));  EPI_DGELU -> (A x) * gelu'(aux)."""
+def pwconv_ex(a_mat, x, bias=None, epi=EPI_NONE, aux=None, transposed=False):
+    """A [M,K] bf16 (or, with transposed=True, At [K,M]) applied over the channel axis of x [B,K,H,W] bf16 with
+    an epilogue: EPI_NONE -> y;  EPI_GELU -> (pre, gelu(pre));  EPI_DGELU -> (A x) * gelu'(aux)."""
     B, K, H, W = x.shape
-    M = a_mat.shape[0]
+    M = a_mat.shape[1] if transposed else a_mat.shape[0]
     y = torch.empty(B, M, H, W, device=x.device, dtype=_BF16)
     y2 = torch.empty_like(y) if epi == EPI_GELU else None
     bp, bflag = _bias_arg(bias)
     call("ppea_pwconv_ex_bf16", ptr(a_mat, _BF16), ptr(x, _BF16), bp, bflag, epi, ptr(aux, _BF16) if aux is not None
-         else None, ptr(y), ptr(y2), B, M, K, H * W, stream_ptr())
+         else None, ptr(y), ptr(y2), B, M, K, H * W, int(transposed), stream_ptr())
     return (y, y2) if epi == EPI_GELU else y
 
 
@@ -607,6 +607,20 @@ def pwgrad(p, q, want_rowsum=True):
     call("ppea_pwgrad_bf16", ptr(p, _BF16), ptr(q, _BF16), ptr(out), ptr(ws), B, M, N, H * W, int(want_rowsum),
          stream_ptr())
     return out[:M * N].view(M, N), (out[M * N:] if want_rowsum else None)
+
+
+def pwgrad_into(p, q, w_shape, w_dtype, taps=1, b_rows=None, b_dtype=None):
+    """Weight (and bias) gradients written straight in parameter layout / dtype by the reduce kernel:
+    dW = sum_{b,pixels} p[b,m,:] q[b,n,:] as `w_shape` (taps = 9: p rows are tap-major, dW in Conv2d layout);
+    db = row sums of p rows `b_rows` = (first, count)."""
+    B, M, H, W = p.shape
+    N = q.shape[1]
+    ws = torch.empty(_abi.lib.ppea_pwgrad_workspace_bytes(B, M, N, H * W) // 4, device=p.device, dtype=_F32)
+    dw = torch.empty(w_shape, device=p.device, dtype=w_dtype)
+    db = torch.empty(b_rows[1], device=p.device, dtype=b_dtype) if b_rows is not None else None
+    call("ppea_pwgrad_ex_bf16", ptr(p, _BF16), ptr(q, _BF16), ptr(ws), B, M, N, H * W, ptr(dw), int(w_dtype == _BF16),
+         taps, ptr(db), int(b_dtype == _BF16), b_rows[0] if b_rows else 0, b_rows[1] if b_rows else 0, stream_ptr())
+    return dw, db
 
 
 def tapsum_fwd(T, bias, Ch):
@@ -631,8 +645,14 @@ def adapter_supported(x, hidden):
             and W % 4 == 0)
 
 
+def _grad_dtype(t):
+    return t.dtype if t.dtype in (_BF16, _F32) else _F32
+
+
 class _MlpAdapterFn(torch.autograd.Function):
-    """`Adapter` (rka.py:20-47): y = W2 gelu(W1 x + b1) + b2 over the channel axis."""
+    """`Adapter` (rka.py:20-47): y = W2 gelu(W1 x + b1) + b2 over the channel axis.  No weight repacking: the
+    data gradients consume the forward matrices through the kernel's transposed-A mode, and the weight / bias
+    gradients leave the reduce kernel in parameter dtype."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
@@ -641,23 +661,26 @@ class _MlpAdapterFn(torch.autograd.Function):
         pre, h = pwconv_ex(w1m, x, b1, EPI_GELU)
         y = pwconv_ex(w2m, h, b2)
         ctx.save_for_backward(x, pre, h, w1m, w2m)
-        ctx.dtypes = (w1.dtype, b1.dtype, w2.dtype, b2.dtype)
+        ctx.dtypes = tuple(_grad_dtype(t) for t in (w1, b1, w2, b2))
+        ctx.shapes = (w1.shape, w2.shape)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, pre, h, w1m, w2m = ctx.saved_tensors
-        dy = dy.contiguous()
-        g = pwconv_ex(w2m.t().contiguous(), dy, None, EPI_DGELU, pre)
-        dw2, db2 = pwgrad(dy, h)
-        dw1, db1 = pwgrad(g, x)
-        dx = pwconv_ex(w1m.t().contiguous(), g) if ctx.needs_input_grad[0] else None
         t = ctx.dtypes
-        return dx, dw1.to(t[0]), db1.to(t[1]), dw2.to(t[2]), db2.to(t[3])
+        C, Ch = w2m.shape
+        dy = dy.contiguous()
+        g = pwconv_ex(w2m, dy, None, EPI_DGELU, pre, transposed=True)          # W2^T dy: At = W2 [C][Ch]
+        dw2, db2 = pwgrad_into(dy, h, ctx.shapes[1], t[2], 1, (0, C), t[3])
+        dw1, db1 = pwgrad_into(g, x, ctx.shapes[0], t[0], 1, (0, Ch), t[1])
+        dx = pwconv_ex(w1m, g, transposed=True) if ctx.needs_input_grad[0] else None
+        return dx, dw1, db1, dw2, db2
 
 
 class _ConvAdapterFn(torch.autograd.Function):
-    """`B_Adapter`, adpt_test 4 (rka.py:49-109): y = W2 gelu(conv3x3(x; W1) + b1) + b2."""
+    """`B_Adapter`, adpt_test 4 (rka.py:49-109): y = W2 gelu(conv3x3(x; W1) + b1) + b2.  One repack per step
+    (W1 -> tap-major [9*Ch][C]); its transpose for the data gradient is the kernel's transposed-A mode."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
@@ -668,27 +691,23 @@ class _ConvAdapterFn(torch.autograd.Function):
         T = pwconv_ex(a1, x)
         pre, h = tapsum_fwd(T, b1, Ch)
         y = pwconv_ex(w2m, h, b2)
-        ctx.save_for_backward(x, pre, h, w1, w2m)
-        ctx.dtypes = (w1.dtype, b1.dtype, w2.dtype, b2.dtype)
+        ctx.save_for_backward(x, pre, h, a1, w2m)
+        ctx.dtypes = tuple(_grad_dtype(t) for t in (w1, b1, w2, b2))
+        ctx.shapes = (w1.shape, w2.shape)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, pre, h, w1, w2m = ctx.saved_tensors
-        Ch, C = w1.shape[0], w1.shape[1]
-        dy = dy.contiguous()
-        g = pwconv_ex(w2m.t().contiguous(), dy, None, EPI_DGELU, pre)
-        dw2, db2 = pwgrad(dy, h)
-        dT = tapsum_bwd(g)
-        da1, rs = pwgrad(dT, x)                                                    # [9*Ch, C], [9*Ch]
-        dw1 = da1.view(3, 3, Ch, C).permute(2, 3, 0, 1)
-        db1 = rs[4 * Ch:5 * Ch]                                                    # centre tap rows == g itself
-        dx = None
-        if ctx.needs_input_grad[0]:
-            a1t = w1.to(_BF16).permute(1, 2, 3, 0).reshape(C, 9 * Ch).contiguous()  # cols t*Ch + m
-            dx = pwconv_ex(a1t, dT)
+        x, pre, h, a1, w2m = ctx.saved_tensors
         t = ctx.dtypes
-        return dx, dw1.to(t[0]), db1.to(t[1]), dw2.to(t[2]), db2.to(t[3])
+        C, Ch = w2m.shape
+        dy = dy.contiguous()
+        g = pwconv_ex(w2m, dy, None, EPI_DGELU, pre, transposed=True)
+        dw2, db2 = pwgrad_into(dy, h, ctx.shapes[1], t[2], 1, (0, C), t[3])
+        dT = tapsum_bwd(g)
+        dw1, db1 = pwgrad_into(dT, x, ctx.shapes[0], t[0], 9, (4 * Ch, Ch), t[1])   # centre-tap rows == g
+        dx = pwconv_ex(a1, dT, transposed=True) if ctx.needs_input_grad[0] else None  # At = a1 [9*Ch][C]
+        return dx, dw1, db1, dw2, db2
 
 
 def mlp_adapter(x, w1, b1, w2, b2):
