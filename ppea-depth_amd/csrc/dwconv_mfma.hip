@@ -117,26 +117,109 @@ __device__ __forceinline__ void stage_planes(uint8_t* tile, const uint16_t* __re
     const int gx = it.x0 - GE::JOFF + cg * 8;
     const bool vec_ok = ((W & 7) == 0) && gx >= 0 && gx + 8 <= W;
     const bool any_col = gx + 8 > 0 && gx < W;
+    constexpr int U = 8;                                       // row pieces in flight per lane
     for (int g = 0; g < it.G; ++g) {
         const uint16_t* plane = src + ((long)(it.n0 + g) * C + c) * (long)H * W;
-        uint8_t* dst = tile + ((long)g * rows_l + r_in) * STRIDE_B + cg * 16;
-        int gy = it.y0 - GE::P + r_in;
-        for (int r = r_in; r < rows_l; r += RPI, gy += RPI, dst += RPI * STRIDE_B) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gy >= 0 && gy < H && any_col) {
-                const uint16_t* rowp = plane + (long)gy * W;
-                if (vec_ok) {
-                    v = *reinterpret_cast<const uint4*>(rowp + gx);
-                } else {
-                    uint16_t e[8];
+        uint8_t* dst0 = tile + ((long)g * rows_l + r_in) * STRIDE_B + cg * 16;
+        const int gy0 = it.y0 - GE::P + r_in;
+        // fast path: every global load is unconditional and in bounds (masked pieces re-read the plane's first
+        // bytes and are zeroed at the LDS store), U of them in flight before the first store -- a load under a
+        // branch would make the compiler drain vmcnt in every iteration, one exposed memory latency per piece.
+        for (int rb = r_in; rb < rows_l; rb += RPI * U) {
+            uint4 v[U];
+            bool ok[U];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) e[k] = (gx + k >= 0 && gx + k < W) ? rowp[gx + k] : (uint16_t)0;
-                    v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
-                    v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+            for (int u = 0; u < U; ++u) {
+                const int gy = gy0 + (rb - r_in) + u * RPI;
+                ok[u] = vec_ok && gy >= 0 && gy < H && (rb + u * RPI) < rows_l;
+                v[u] = *reinterpret_cast<const uint4*>(ok[u] ? plane + (long)gy * W + gx : plane);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (rb + u * RPI < rows_l) {
+                    const uint4 w = make_uint4(ok[u] ? v[u].x : 0u, ok[u] ? v[u].y : 0u, ok[u] ? v[u].z : 0u,
+                                               ok[u] ? v[u].w : 0u);
+                    *reinterpret_cast<uint4*>(dst0 + (long)(rb - r_in + u * RPI) * STRIDE_B) = w;
                 }
             }
-            *reinterpret_cast<uint4*>(dst) = v;
         }
+        // slow path, only for column groups that straddle the left / right image edge (or W % 8 != 0)
+        if (!vec_ok && any_col) {
+            uint8_t* dst = dst0;
+            int gy = gy0;
+            for (int r = r_in; r < rows_l; r += RPI, gy += RPI, dst += RPI * STRIDE_B) {
+                if (gy < 0 || gy >= H) continue;
+                const uint16_t* rowp = plane + (long)gy * W;
+                uint16_t e[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[k] = (gx + k >= 0 && gx + k < W) ? rowp[gx + k] : (uint16_t)0;
+                uint4 v;
+                v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
+                v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+                *reinterpret_cast<uint4*>(dst) = v;
+            }
+        }
+    }
+}
+
+// ---- prefetched staging -------------------------------------------------------------------------------
+// When an item covers whole planes (one band) the halo rows above / below every staged image are zero for
+// EVERY item of the wave: they are cleared once and never written again, and an item stages only the rows
+// that exist in the image -- at most SU 16-byte pieces per lane.  Those pieces are loaded into registers
+// one item AHEAD (the loads are in flight under the previous item's MFMAs) and written to LDS when the tile
+// region is free again.  Needs W % 8 == 0 (every column group is wholly inside or wholly outside the image).
+constexpr int SU = 16;
+
+template <int K, int NSEG>
+__device__ __forceinline__ int stage_pieces(const Item& it, int H) {       // per-lane slots the item needs
+    constexpr int RPI = 64 / (Seg<K, NSEG>::WL / 8);
+    const int lo = max(0, it.y0 - Geo<K>::P), hi = min(H, it.y0 + it.rows + Geo<K>::P);
+    return it.G * ((hi - lo + RPI - 1) / RPI);
+}
+
+template <int K, int NSEG>
+__device__ __forceinline__ void stage_load(uint4 (&v)[SU], const uint16_t* __restrict__ src, const Item& it, int C,
+                                           int c, int H, int W, int lane) {
+    using GE = Geo<K>;
+    constexpr int CG = Seg<K, NSEG>::WL / 8, RPI = 64 / CG;
+    const int r_in = lane / CG, cg = lane - r_in * CG;
+    const int gx = it.x0 - GE::JOFF + cg * 8;
+    const bool col_ok = r_in < RPI && gx >= 0 && gx + 8 <= W;
+    const int lo = max(0, it.y0 - GE::P), hi = min(H, it.y0 + it.rows + GE::P);
+    const int ppv = (hi - lo + RPI - 1) / RPI;
+    const uint16_t* base = src + ((long)it.n0 * C + c) * (long)H * W;
+    int g = 0, j = 0;
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+        const int gy = lo + j * RPI + r_in;
+        const bool ok = col_ok && g < it.G && gy < hi;
+        v[u] = *reinterpret_cast<const uint4*>(ok ? base + ((long)g * C * H + gy) * W + gx : src);
+        if (++j == ppv) { j = 0; ++g; }
+    }
+}
+
+template <int K, int NSEG>
+__device__ __forceinline__ void stage_store(const uint4 (&v)[SU], uint8_t* tile, const Item& it, int H, int W,
+                                            int lane) {
+    using GE = Geo<K>;
+    constexpr int CG = Seg<K, NSEG>::WL / 8, RPI = 64 / CG;
+    constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
+    const int r_in = lane / CG, cg = lane - r_in * CG;
+    const int gx = it.x0 - GE::JOFF + cg * 8;
+    const bool col_ok = gx >= 0 && gx + 8 <= W;
+    const int lo = max(0, it.y0 - GE::P), hi = min(H, it.y0 + it.rows + GE::P);
+    const int ppv = (hi - lo + RPI - 1) / RPI;
+    const int rows_l = it.rows + K - 1;
+    int g = 0, j = 0;
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+        const int gy = lo + j * RPI + r_in;
+        if (r_in < RPI && g < it.G && gy < hi) {
+            const uint4 w = make_uint4(col_ok ? v[u].x : 0u, col_ok ? v[u].y : 0u, col_ok ? v[u].z : 0u,
+                                       col_ok ? v[u].w : 0u);
+            *reinterpret_cast<uint4*>(tile + ((long)g * rows_l + (gy - (it.y0 - GE::P))) * STRIDE_B + cg * 16) = w;
+        }
+        if (++j == ppv) { j = 0; ++g; }
     }
 }
 
@@ -155,51 +238,35 @@ __device__ __forceinline__ void ds_read128_async(bf16x8& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
 }
 
-template <int N, int CNT>
-__device__ __forceinline__ void wait_lds(bf16x8 (&a)[N]) {
-    static_assert(N == 8 || N == 5, "group sizes used by tile_mac");
-    if constexpr (N == 8)
-        asm volatile("s_waitcnt lgkmcnt(%8)"
-                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-                     : "i"(CNT));
-    else
-        asm volatile("s_waitcnt lgkmcnt(%5)"
-                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4])
-                     : "i"(CNT));
+// Software pipeline of one tile: the A fragments stream through a ring of RING registers, the read of
+// fragment I + DIST is issued right after MFMA I, and every wait names exactly how many younger reads may
+// still be in flight (LDS reads of one wave return in order; lgkmcnt is a 4-bit counter, so DIST <= 15).
+// Two accumulators alternate so that consecutive MFMAs never wait on each other's result.
+constexpr int DIST = 12, RING = 13;
+
+template <int KK, int NS, int ROW0, int STRIDE_B, int I>
+__device__ __forceinline__ void issue_read(bf16x8 (&a)[RING], uint32_t abase) {
+    if constexpr (I < KK * NS) {
+        constexpr int ky = I / NS, sidx = I % NS;
+        ds_read128_async<(ky + ROW0) * STRIDE_B + sidx * 64>(a[I % RING], abase);
+    }
 }
 
-template <int KK, int NS, int ROW0, int STRIDE_B, int GRP, int G, int I>
-__device__ __forceinline__ void issue_one(bf16x8 (&a)[GRP * NS], uint32_t abase) {
-    constexpr int r = I / NS, sidx = I % NS, ky = G * GRP + r;
-    if constexpr (ky < KK) ds_read128_async<(ky + ROW0) * STRIDE_B + sidx * 64>(a[I], abase);
+template <int KK, int NS, int ROW0, int STRIDE_B, int... Is>
+__device__ __forceinline__ void issue_first(bf16x8 (&a)[RING], uint32_t abase, std::integer_sequence<int, Is...>) {
+    (issue_read<KK, NS, ROW0, STRIDE_B, Is>(a, abase), ...);
 }
 
-template <int KK, int NS, int ROW0, int STRIDE_B, int GRP, int G, int... Is>
-__device__ __forceinline__ void issue_all(bf16x8 (&a)[GRP * NS], uint32_t abase, std::integer_sequence<int, Is...>) {
-    (issue_one<KK, NS, ROW0, STRIDE_B, GRP, G, Is>(a, abase), ...);
-}
-
-constexpr int group_reads(int KK, int NS, int GRP, int g) {
-    const int rows = (KK - g * GRP) < GRP ? (KK - g * GRP) : GRP;
-    return rows > 0 ? rows * NS : 0;
-}
-
-template <int KK, int NS, int ROW0, int STRIDE_B, int GRP, int G>
-__device__ __forceinline__ void mac_groups(f32x4& acc, bf16x8 (&cur)[GRP * NS], bf16x8 (&nxt)[GRP * NS],
-                                           uint32_t abase, const bf16x8 (&bf)[KK][NS]) {
-    constexpr int NG = (KK + GRP - 1) / GRP;
-    if constexpr (G < NG) {
-        if constexpr (G + 1 < NG)
-            issue_all<KK, NS, ROW0, STRIDE_B, GRP, G + 1>(nxt, abase, std::make_integer_sequence<int, GRP * NS>{});
-        wait_lds<GRP * NS, group_reads(KK, NS, GRP, G + 1)>(cur);
-#pragma unroll
-        for (int r = 0; r < GRP; ++r)
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int ky = G * GRP + r;
-                if (ky < KK) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[r * NS + s], bf[ky][s], acc, 0, 0, 0);
-            }
-        mac_groups<KK, NS, ROW0, STRIDE_B, GRP, G + 1>(acc, nxt, cur, abase, bf);
+template <int KK, int NS, int ROW0, int STRIDE_B, int I>
+__device__ __forceinline__ void mac_step(f32x4 (&acc)[2], bf16x8 (&a)[RING], uint32_t abase,
+                                         const bf16x8 (&bf)[KK][NS]) {
+    if constexpr (I < KK * NS) {
+        constexpr int TOTAL = KK * NS;
+        constexpr int younger = (TOTAL - 1 - I) < (DIST - 1) ? (TOTAL - 1 - I) : (DIST - 1);
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[I % RING]) : "i"(younger));
+        acc[I & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[I % RING], bf[I / NS][I % NS], acc[I & 1], 0, 0, 0);
+        issue_read<KK, NS, ROW0, STRIDE_B, I + DIST>(a, abase);
+        mac_step<KK, NS, ROW0, STRIDE_B, I + 1>(acc, a, abase, bf);
     }
 }
 
@@ -208,10 +275,11 @@ __device__ __forceinline__ void mac_groups(f32x4& acc, bf16x8 (&cur)[GRP * NS], 
 // the tile) + 16 * (lane >> 4); ROW0 = extra row offset (small kernel inside the big halo).
 template <int KK, int NS, int ROW0, int STRIDE_B>
 __device__ __forceinline__ void tile_mac(f32x4& acc, uint32_t abase, const bf16x8 (&bf)[KK][NS]) {
-    constexpr int GRP = (NS == 2) ? 4 : 5;
-    bf16x8 a0[GRP * NS], a1[GRP * NS];
-    issue_all<KK, NS, ROW0, STRIDE_B, GRP, 0>(a0, abase, std::make_integer_sequence<int, GRP * NS>{});
-    mac_groups<KK, NS, ROW0, STRIDE_B, GRP, 0>(acc, a0, a1, abase, bf);
+    bf16x8 a[RING];
+    f32x4 acc2[2] = {acc, {0.f, 0.f, 0.f, 0.f}};
+    issue_first<KK, NS, ROW0, STRIDE_B>(a, abase, std::make_integer_sequence<int, DIST>{});
+    mac_step<KK, NS, ROW0, STRIDE_B, 0>(acc2, a, abase, bf);
+    acc = acc2[0] + acc2[1];
 }
 
 // Per M-tile: element offsets of this lane's four output rows (-1 = padding row).
@@ -297,30 +365,53 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     constexpr int SM_ROW0 = GE::P - GS::P;                  // small-kernel rows inside the big halo
     constexpr int SM_COLB = (GE::JOFF - GS::JOFF) * 2;      // byte offset of its first chunk
 
-    for (int k = 0; k < ipw; ++k) {
-        const int item_id = first_item + k;                 // wave-uniform
-        if (item_id >= items_per_channel) break;
-        Item it;                                            // item = (plane group or row band, column segment)
-        {
-            const int seg = item_id % segs;
-            const int gb = item_id / segs;
-            it.x0 = seg * 16 * NSEG;
-            if (G > 1) {                                    // G small planes stacked along M, whole height
-                it.n0 = gb * G;
-                it.G = min(G, N - it.n0);
-                it.y0 = 0;
-                it.rows = H;
-            } else {                                        // one plane, bands of `band` rows
-                it.n0 = gb / bands;
-                it.G = 1;
-                it.y0 = (gb - it.n0 * bands) * band;
-                it.rows = min(band, H - it.y0);
-            }
+    auto make_item = [&](int item_id, Item& it) -> bool {    // item = (plane group or row band, column segment)
+        if (item_id >= items_per_channel || item_id >= first_item + ipw) return false;
+        const int seg = item_id % segs;
+        const int gb = item_id / segs;
+        it.x0 = seg * 16 * NSEG;
+        if (G > 1) {                                        // G small planes stacked along M, whole height
+            it.n0 = gb * G;
+            it.G = min(G, N - it.n0);
+            it.y0 = 0;
+            it.rows = H;
+        } else {                                            // one plane, bands of `band` rows
+            it.n0 = gb / bands;
+            it.G = 1;
+            it.y0 = (gb - it.n0 * bands) * band;
+            it.rows = min(band, H - it.y0);
         }
+        return true;
+    };
+    int done = 0;
+    Item it;
+    bool have = make_item(first_item, it);
+    // prefetched staging (see stage_load): whole planes per item, aligned columns, few enough pieces
+    const bool fast = have && bands == 1 && (W & 7) == 0 && stage_pieces<K, NSEG>(it, H) * (G > 1 ? G : 1) / it.G <= SU;
+    uint4 pre[SU];
+    if (fast) {
+        for (int off = lane * 16; off < NT_IN * tile_bytes; off += 64 * 16)
+            *reinterpret_cast<uint4*>(tile0 + off) = make_uint4(0, 0, 0, 0);
+        stage_load<K, NSEG>(pre, in0, it, C, c, H, W, lane);
+    }
+
+    while (have) {
         // The tile is wave-private: LDS operations of one wave execute in order, so the staging writes
         // below are ordered after the previous item's (already waited-for) reads and before this item's.
-        stage_planes<K, NSEG>(tile0, in0, it, C, c, H, W, lane);
-        if constexpr (NT_IN == 2) stage_planes<K, NSEG>(tile1, in1, it, C, c, H, W, lane);
+        Item nxt;
+        const bool have_next = make_item(first_item + (++done), nxt);
+        if (fast) {
+            stage_store<K, NSEG>(pre, tile0, it, H, W, lane);
+            if constexpr (NT_IN == 2) {
+                uint4 second[SU];
+                stage_load<K, NSEG>(second, in1, it, C, c, H, W, lane);
+                stage_store<K, NSEG>(second, tile1, it, H, W, lane);
+            }
+            if (have_next) stage_load<K, NSEG>(pre, in0, nxt, C, c, H, W, lane);   // lands during the MFMAs below
+        } else {
+            stage_planes<K, NSEG>(tile0, in0, it, C, c, H, W, lane);
+            if constexpr (NT_IN == 2) stage_planes<K, NSEG>(tile1, in1, it, C, c, H, W, lane);
+        }
         asm volatile("" ::: "memory");      // compiler fence: staging stores stay above the asm LDS reads
 
         const int rows_l = it.rows + K - 1;                 // LDS rows per stacked image (with halo)
@@ -352,6 +443,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
             }
         }
         asm volatile("" ::: "memory");      // next item's staging stores stay below this item's LDS reads
+        it = nxt;
+        have = have_next;
     }
 }
 

@@ -1,0 +1,26 @@
+"""Launches for the PMC passes (rocprofv3 --pmc ... -- python3 tools/pmc_target.py): the 31x31 (+5x5) bf16 depthwise
+conv forward / dgrad at stage 0 and the stage-2 pointwise GEMM shapes.  GPU box only."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ppea-depth_amd"))
+from ppeadepth import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+B = 12
+x = torch.randn(B, 128, 48, 160, device=dev).bfloat16().requires_grad_(True)
+wb = torch.randn(128, 1, 31, 31, device=dev) / 31
+ws = torch.randn(128, 1, 5, 5, device=dev) / 5
+for _ in range(4):
+    yb, ys = ops.dwconv_lk(x, wb, ws)
+    torch.autograd.grad((yb, ys), x, (torch.ones_like(yb), torch.ones_like(ys)))
+for (K, H, W, M) in [(512, 12, 40, 512), (2048, 12, 40, 512), (512, 12, 40, 2048), (128, 48, 160, 128)]:
+    xx = torch.randn(B, K, H, W, device=dev).bfloat16()
+    a = (torch.randn(M, K, device=dev) / K ** 0.5).bfloat16()
+    for _ in range(3):
+        ops.pwconv_raw(a, xx)
+torch.cuda.synchronize()
+print("done")
