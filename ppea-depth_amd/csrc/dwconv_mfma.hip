@@ -282,6 +282,45 @@ __device__ __forceinline__ void tile_mac(f32x4& acc, uint32_t abase, const bf16x
     acc = acc2[0] + acc2[1];
 }
 
+// ---- cross-tile stream -----------------------------------------------------------------------------------
+// One tile = TOTAL = K*NS (+KS) steps, each one A read + one MFMA.  The read for step I + DIST is issued right
+// after MFMA I; for the last DIST steps of a tile those are the FIRST reads of the next tile (into the other
+// ring), so the LDS pipe never drains between tiles and a tile's epilogue (convert + stores) runs under the
+// next tile's reads.  Step I < K*NS: big filter row I / NS, chunk I % NS at `big`; the KS small-filter steps
+// read at `small` (MODE 0: own accumulator / second output; MODE 1: second input, same accumulator).
+struct TileBase { uint32_t big, small; };
+
+template <int K, int KS, int NS, int STRIDE_B, int SM_ROW0, int J>
+__device__ __forceinline__ void stream_read(bf16x8& slot, const TileBase& tb) {
+    if constexpr (J < K * NS) ds_read128_async<(J / NS) * STRIDE_B + (J % NS) * 64>(slot, tb.big);
+    else ds_read128_async<(J - K * NS + SM_ROW0) * STRIDE_B>(slot, tb.small);
+}
+
+template <int K, int KS, int NS, int STRIDE_B, int SM_ROW0, int... Is>
+__device__ __forceinline__ void stream_first(bf16x8 (&ring)[RING], const TileBase& tb, std::integer_sequence<int, Is...>) {
+    (stream_read<K, KS, NS, STRIDE_B, SM_ROW0, Is>(ring[Is % RING], tb), ...);
+}
+
+template <int K, int KS, int MODE, int NS, int STRIDE_B, int SM_ROW0, int I>
+__device__ __forceinline__ void stream_step(f32x4 (&accb)[2], f32x4& accs, bf16x8 (&cur)[RING], bf16x8 (&nxt)[RING],
+                                            const TileBase& tc, const TileBase& tn, const bf16x8 (&bfb)[K][NS],
+                                            const bf16x8 (&bfs)[(KS > 0 ? KS : 1)][1]) {
+    constexpr int TOTAL = K * NS + KS;
+    if constexpr (I < TOTAL) {
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[I % RING]) : "i"(DIST - 1));
+        if constexpr (I < K * NS)
+            accb[I & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[I % RING], bfb[I / NS][I % NS], accb[I & 1], 0, 0, 0);
+        else if constexpr (MODE == 0)
+            accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[I % RING], bfs[I - K * NS][0], accs, 0, 0, 0);
+        else
+            accb[I & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[I % RING], bfs[I - K * NS][0], accb[I & 1], 0, 0, 0);
+        constexpr int J = I + DIST;
+        if constexpr (J < TOTAL) stream_read<K, KS, NS, STRIDE_B, SM_ROW0, J>(cur[J % RING], tc);
+        else stream_read<K, KS, NS, STRIDE_B, SM_ROW0, J - TOTAL>(nxt[(J - TOTAL) % RING], tn);
+        stream_step<K, KS, MODE, NS, STRIDE_B, SM_ROW0, I + 1>(accb, accs, cur, nxt, tc, tn, bfb, bfs);
+    }
+}
+
 // Per M-tile: element offsets of this lane's four output rows (-1 = padding row).
 struct RowOffs { int off[4]; };
 
@@ -418,30 +457,42 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
         const int ntiles_x = min(NSEG, (W - it.x0 + 15) / 16);
         const int mrows = it.G * it.rows;
         const int ntiles_m = (mrows + 15) / 16;
-        for (int mt = 0; mt < ntiles_m; ++mt) {
+        // tiles of the item in (mt, nt) order as ONE stream (see stream_step); two rings alternate by tile parity
+        auto tile_base = [&](int mt, int nt) -> TileBase {
             // this lane's A row -> first LDS row of its window (clamped for padding rows)
             const int m = min(mt * 16 + (lane & 15), mrows - 1);
             const int g = m / it.rows, y = m - g * it.rows;
-            const long aoff = (long)(g * rows_l + y) * STRIDE_B + 16 * (lane >> 4);
-            const uint32_t arow0 = lds_addr(tile0 + aoff);
-            const uint32_t arow1 = lds_addr(tile1 + aoff);
-            const RowOffs ro = row_offsets(it, C, c, H, W, mt, lane);
-            for (int nt = 0; nt < ntiles_x; ++nt) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                tile_mac<K, GE::NS, 0, STRIDE_B>(acc, arow0 + nt * 32, bf_big);
-                if constexpr (MODE == 0) {
-                    store_tile(out0, acc, ro, W, it.x0 + nt * 16, lane);
-                    if constexpr (KS > 0) {
-                        f32x4 acs = {0.f, 0.f, 0.f, 0.f};
-                        tile_mac<KS, 1, SM_ROW0, STRIDE_B>(acs, arow0 + nt * 32 + SM_COLB, bf_small);
-                        store_tile(out1, acs, ro, W, it.x0 + nt * 16, lane);
-                    }
-                } else {
-                    if constexpr (KS > 0) tile_mac<KS, 1, SM_ROW0, STRIDE_B>(acc, arow1 + nt * 32 + SM_COLB, bf_small);
-                    store_tile(out0, acc, ro, W, it.x0 + nt * 16, lane);
-                }
-            }
+            const long aoff = (long)(g * rows_l + y) * STRIDE_B + 16 * (lane >> 4) + nt * 32;
+            TileBase tb;
+            tb.big = lds_addr(tile0 + aoff);
+            tb.small = lds_addr((MODE == 1 ? tile1 : tile0) + aoff) + SM_COLB;
+            return tb;
+        };
+        const int ntiles = ntiles_m * ntiles_x;
+        bf16x8 ringA[RING], ringB[RING];
+        int mt = 0, nt = 0;
+        TileBase tc = tile_base(0, 0);
+        stream_first<K, KS, GE::NS, STRIDE_B, SM_ROW0>(ringA, tc, std::make_integer_sequence<int, DIST>{});
+        RowOffs ro = row_offsets(it, C, c, H, W, 0, lane);
+        auto one_tile = [&](bf16x8 (&cur)[RING], bf16x8 (&nxt_ring)[RING], int t) {
+            int mt2 = mt, nt2 = nt + 1;
+            if (nt2 == ntiles_x) { nt2 = 0; ++mt2; }
+            const bool last = t + 1 >= ntiles;
+            const TileBase tn = last ? tc : tile_base(mt2, nt2);        // last tile: harmless re-reads, drained below
+            f32x4 accb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            f32x4 accs = {0.f, 0.f, 0.f, 0.f};
+            stream_step<K, KS, MODE, GE::NS, STRIDE_B, SM_ROW0, 0>(accb, accs, cur, nxt_ring, tc, tn, bf_big, bf_small);
+            const f32x4 acc = accb[0] + accb[1];
+            store_tile(out0, acc, ro, W, it.x0 + nt * 16, lane);
+            if constexpr (MODE == 0 && KS > 0) store_tile(out1, accs, ro, W, it.x0 + nt * 16, lane);
+            if (mt2 != mt && !last) ro = row_offsets(it, C, c, H, W, mt2, lane);
+            mt = mt2; nt = nt2; tc = tn;
+        };
+        for (int t = 0; t < ntiles; t += 2) {
+            one_tile(ringA, ringB, t);
+            if (t + 1 < ntiles) one_tile(ringB, ringA, t + 1);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the look-ahead reads of the last tile
         asm volatile("" ::: "memory");      // next item's staging stores stay below this item's LDS reads
         it = nxt;
         have = have_next;
