@@ -122,8 +122,8 @@ __device__ __forceinline__ void stage_planes(uint8_t* tile, const uint16_t* __re
         const uint16_t* plane = src + ((long)(it.n0 + g) * C + c) * (long)H * W;
         uint8_t* dst0 = tile + ((long)g * rows_l + r_in) * STRIDE_B + cg * 16;
         const int gy0 = it.y0 - GE::P + r_in;
-        // fast path: every global load is unconditional and in bounds (masked pieces re-read the plane's first
-        // bytes and are zeroed at the LDS store), U of them in flight before the first store -- a load under a
+        // fast path: every global load is unconditional and in bounds (masked pieces re-read the tensor's first
+        // 16 bytes -- NOT the plane's: a 2x3 plane is 12 bytes -- and are zeroed at the LDS store), U of them in flight before the first store -- a load under a
         // branch would make the compiler drain vmcnt in every iteration, one exposed memory latency per piece.
         for (int rb = r_in; rb < rows_l; rb += RPI * U) {
             uint4 v[U];
@@ -132,7 +132,7 @@ __device__ __forceinline__ void stage_planes(uint8_t* tile, const uint16_t* __re
             for (int u = 0; u < U; ++u) {
                 const int gy = gy0 + (rb - r_in) + u * RPI;
                 ok[u] = vec_ok && gy >= 0 && gy < H && (rb + u * RPI) < rows_l;
-                v[u] = *reinterpret_cast<const uint4*>(ok[u] ? plane + (long)gy * W + gx : plane);
+                v[u] = *reinterpret_cast<const uint4*>(ok[u] ? plane + (long)gy * W + gx : src);   // src: 16 B always in bounds
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -506,6 +506,7 @@ int launch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const u
     constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
     constexpr int FILT_BYTES = (packed_elems(K) + (KS > 0 ? packed_elems(KS) : 0)) * 2;
     if ((long)N * C * H * W >= (1L << 31)) return PPEA_ERR_UNSUPPORTED;      // 32-bit element offsets
+    if ((long)N * C * H * W < 8) return PPEA_ERR_UNSUPPORTED;                // masked lanes read the first 16 bytes
     // largest band / stacking whose per-wave region fits four times into the 160 KB of LDS
     int band = 0, G = 1, tile_bytes = 0, region = 0;
     for (int cand : {48, 32, 16}) {

@@ -3,6 +3,8 @@ forward/backward below is one (or two) kernel launches on the current HIP stream
 
 Reference call sites are cited per op (paths relative to /root/reference/ppeadepth/).
 """
+import weakref
+
 import torch
 
 from . import _abi
@@ -43,18 +45,20 @@ _MFMA_K = (31, 29, 27, 13)
 
 
 def _packed_filter(w, flip):
-    """uint8 buffer with the bf16 Toeplitz source image of w [C,1,K,K]; rebuilt when w changes in place."""
-    key = (w.data_ptr(), w.device.index, int(flip))
+    """uint8 buffer with the bf16 Toeplitz source image of w [C,1,K,K]; rebuilt when w changes in place.
+    Keyed by the tensor object (weak reference), not by its address: a freed weight's address can be handed to
+    another model's weight."""
+    key = (id(w), int(flip))
     ver = w._version
     hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == ver and hit[2] == tuple(w.shape):
+    if hit is not None and hit[3]() is w and hit[0] == ver and hit[2] == tuple(w.shape):
         return hit[1]
     C, K = w.shape[0], w.shape[-1]
     nbytes = _abi.lib.ppea_dwconv_lk_packed_bytes(C, K)
     buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     wf = w.detach().to(_F32).contiguous()
     call("ppea_dwconv_lk_pack_bf16", ptr(wf), ptr(buf), C, K, int(flip), stream_ptr())
-    _PACK_CACHE[key] = (ver, buf, tuple(w.shape))
+    _PACK_CACHE[key] = (ver, buf, tuple(w.shape), weakref.ref(w, lambda _r, k=key: _PACK_CACHE.pop(k, None)))
     return buf
 
 
@@ -525,14 +529,14 @@ _PW_CACHE = {}
 
 
 def _pw_matrices(w):
-    """(W [Cout][Cin] bf16, W^T [Cin][Cout] bf16) of a frozen 1x1 conv weight, cached per version."""
-    key = (w.data_ptr(), w.device.index)
+    """(W [Cout][Cin] bf16, W^T [Cin][Cout] bf16) of a frozen 1x1 conv weight, cached per tensor object/version."""
+    key = id(w)
     hit = _PW_CACHE.get(key)
-    if hit is not None and hit[0] == w._version and hit[3] == tuple(w.shape):
+    if hit is not None and hit[4]() is w and hit[0] == w._version and hit[3] == tuple(w.shape):
         return hit[1], hit[2]
     m = w.detach().reshape(w.shape[0], w.shape[1]).to(_BF16).contiguous()
     mt = m.t().contiguous()
-    _PW_CACHE[key] = (w._version, m, mt, tuple(w.shape))
+    _PW_CACHE[key] = (w._version, m, mt, tuple(w.shape), weakref.ref(w, lambda _r, k=key: _PW_CACHE.pop(k, None)))
     return m, mt
 
 

@@ -82,6 +82,7 @@ def test_dwconv_golden_reference(device, golden):
 
 
 @pytest.mark.parametrize("K,N,C,H,W", [(31, 3, 4, 48, 160), (29, 4, 4, 24, 80), (27, 5, 4, 12, 40), (13, 7, 4, 6, 20),
+                                       (13, 2, 64, 2, 3), (27, 2, 32, 4, 6), (29, 2, 16, 8, 12), (31, 2, 8, 16, 24),
                                        (31, 2, 3, 48, 128), (29, 2, 3, 24, 64), (27, 3, 3, 12, 32), (13, 3, 3, 6, 16),
                                        (31, 2, 2, 70, 37), (27, 1, 2, 33, 90), (13, 2, 2, 17, 9), (31, 1, 1, 1, 1),
                                        (31, 2, 2, 128, 256)])
