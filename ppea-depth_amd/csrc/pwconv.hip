@@ -204,9 +204,10 @@ int launch_pw(const void* A, const void* X, const void* bias, int bias_bf16, con
     hipLaunchKernelGGL((pwconv_kernel<BM_, WM_, WN_, EPI, TA>), dim3(nb, (M + BM_ - 1) / BM_, B), dim3(256), 0, st, \
                        (const uint16_t*)A, (const uint16_t*)X, bias, bias_bf16, (const uint16_t*)aux, (uint16_t*)Y, \
                        (uint16_t*)Y2, M, K, HW)
+    const long blocks64 = (long)nb * ((M + 63) / 64) * B;
     if (M >= 128 && blocks128 >= 512) PW_LAUNCH(128, 2, 2);
-    else if (M > 32) PW_LAUNCH(64, 2, 2);
-    else PW_LAUNCH(32, 1, 4);
+    else if (M > 32 && blocks64 >= 256) PW_LAUNCH(64, 2, 2);
+    else PW_LAUNCH(32, 1, 4);            // few tiles: more, smaller workgroups (one per CU at least)
 #undef PW_LAUNCH
     return launch_status();
 }

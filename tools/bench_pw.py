@@ -14,7 +14,8 @@ def timeit(fn, iters=20):
 
 shapes = [(12, 128, 48, 160, 128), (12, 128, 48, 160, 512), (12, 512, 48, 160, 128),
           (12, 512, 12, 40, 512), (12, 512, 12, 40, 2048), (12, 2048, 12, 40, 512),
-          (12, 1024, 6, 20, 4096), (12, 256, 24, 80, 1024)]
+          (12, 1024, 6, 20, 4096), (12, 256, 24, 80, 1024), (12, 512, 12, 40, 128), (12, 128, 12, 40, 512),
+          (12, 1024, 6, 20, 1024)]
 for (B, Ci, H, W, Co) in shapes:
     x = torch.randn(B, Ci, H, W, device=dev, dtype=torch.bfloat16, requires_grad=True)
     w = (torch.randn(Co, Ci, 1, 1, device=dev) / Ci ** 0.5).bfloat16()
