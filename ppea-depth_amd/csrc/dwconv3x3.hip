@@ -68,6 +68,132 @@ __global__ __launch_bounds__(256) void dw3_bwd(const T* __restrict__ dy, const f
     }
 }
 
+
+// ---- bf16, 8 outputs per thread ---------------------------------------------------------------------------
+// The stem runs these at 96x320 / 192x640 on [12,128,...] tensors (94 MB in, 94 MB out): one 16-byte load per
+// input row piece (+ one scalar per side), one 16-byte store; the row taps stay in registers.
+struct Bf8 { float v[8]; };
+__device__ __forceinline__ Bf8 ld8(const uint16_t* p) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    Bf8 r;
+    r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+    r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+    r.v[4] = __uint_as_float(u.z << 16); r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+    r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+    return r;
+}
+__device__ __forceinline__ void st8(uint16_t* p, const float (&a)[8]) {
+    uint32_t h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = f32_to_bf16(a[i]);
+    *reinterpret_cast<uint4*>(p) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+}
+
+// stride 1 (forward, and data gradient with the taps reversed by the caller flag FLIP): W % 8 == 0
+template <bool FLIP>
+__global__ __launch_bounds__(256) void dw3v_s1(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                               uint16_t* __restrict__ y, int C, int H, int W, long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int W8 = W >> 3;
+    const int x0 = (int)(idx % W8) * 8;
+    const int oy = (int)((idx / W8) % H);
+    const long plane = idx / ((long)W8 * H);
+    const float* wc = w + (plane % C) * 9;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = FLIP ? wc[8 - i] : wc[i];
+    const uint16_t* xp = x + plane * (long)H * W;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int iy = oy - 1 + u;
+        if (iy < 0 || iy >= H) continue;
+        const uint16_t* row = xp + (long)iy * W;
+        const Bf8 c = ld8(row + x0);
+        float in[10];
+        in[0] = x0 > 0 ? bf16_to_f32(row[x0 - 1]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) in[j + 1] = c.v[j];
+        in[9] = x0 + 8 < W ? bf16_to_f32(row[x0 + 8]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc[j] = fmaf(k[u * 3 + 2], in[j + 2], fmaf(k[u * 3 + 1], in[j + 1], fmaf(k[u * 3], in[j], acc[j])));
+    }
+    st8(y + (plane * H + oy) * (long)W + x0, acc);
+}
+
+// stride 2 forward: Wo % 8 == 0, W == 2 * Wo
+__global__ __launch_bounds__(256) void dw3v_s2_fwd(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                   uint16_t* __restrict__ y, int C, int H, int W, int Ho, int Wo,
+                                                   long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int W8 = Wo >> 3;
+    const int x0 = (int)(idx % W8) * 8;
+    const int oy = (int)((idx / W8) % Ho);
+    const long plane = idx / ((long)W8 * Ho);
+    const float* wc = w + (plane % C) * 9;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = wc[i];
+    const uint16_t* xp = x + plane * (long)H * W;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int iy = 2 * oy - 1 + u;
+        if (iy < 0 || iy >= H) continue;
+        const uint16_t* row = xp + (long)iy * W + 2 * x0;
+        const Bf8 a = ld8(row), b = ld8(row + 8);
+        float in[17];
+        in[0] = x0 > 0 ? bf16_to_f32(row[-1]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { in[j + 1] = a.v[j]; in[j + 9] = b.v[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc[j] = fmaf(k[u * 3 + 2], in[2 * j + 2], fmaf(k[u * 3 + 1], in[2 * j + 1], fmaf(k[u * 3], in[2 * j], acc[j])));
+    }
+    st8(y + (plane * Ho + oy) * (long)Wo + x0, acc);
+}
+
+// stride 2 data gradient: dx[iy][ix] = sum w[u][v] dy[(iy+1-u)/2][(ix+1-v)/2] over even numerators; W % 8 == 0
+__global__ __launch_bounds__(256) void dw3v_s2_bwd(const uint16_t* __restrict__ dy, const float* __restrict__ w,
+                                                   uint16_t* __restrict__ dx, int C, int H, int W, int Ho, int Wo,
+                                                   long total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int W8 = W >> 3;
+    const int x0 = (int)(idx % W8) * 8;
+    const int iy = (int)((idx / W8) % H);
+    const long plane = idx / ((long)W8 * H);
+    const float* wc = w + (plane % C) * 9;
+    float k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = wc[i];
+    const uint16_t* dp = dy + plane * (long)Ho * Wo;
+    const int ox0 = x0 >> 1;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int ty = iy + 1 - u;
+        if (ty < 0 || (ty & 1)) continue;
+        const int oy = ty >> 1;
+        if (oy >= Ho) continue;
+        const uint16_t* row = dp + (long)oy * Wo + ox0;
+        const uint2 q = *reinterpret_cast<const uint2*>(row);
+        float d[5];
+        d[0] = __uint_as_float(q.x << 16); d[1] = __uint_as_float(q.x & 0xffff0000u);
+        d[2] = __uint_as_float(q.y << 16); d[3] = __uint_as_float(q.y & 0xffff0000u);
+        d[4] = ox0 + 4 < Wo ? bf16_to_f32(row[4]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if ((j & 1) == 0) acc[j] = fmaf(k[u * 3 + 1], d[j >> 1], acc[j]);                 // ix even: v = 1
+            else acc[j] = fmaf(k[u * 3 + 2], d[(j - 1) >> 1], fmaf(k[u * 3], d[(j + 1) >> 1], acc[j]));   // v = 2, 0
+        }
+    }
+    st8(dx + (plane * H + iy) * (long)W + x0, acc);
+}
+
 template <typename T>
 int run(bool bwd, const void* a, const float* w, void* o, int N, int C, int H, int W, int stride, void* stream) {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2) || (long)N * C > 65535L * 32)
@@ -75,6 +201,30 @@ int run(bool bwd, const void* a, const float* w, void* o, int N, int C, int H, i
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const long planes = (long)N * C;
     if (planes > 65535) return PPEA_ERR_UNSUPPORTED;
+    if constexpr (sizeof(T) == 2) {                        // bf16: 8 outputs per thread when the rows allow it
+        hipStream_t st = (hipStream_t)stream;
+        const uint16_t* in = (const uint16_t*)a;
+        uint16_t* out = (uint16_t*)o;
+        if (stride == 1 && (W & 7) == 0) {
+            const long total = planes * H * (W >> 3);
+            const unsigned blocks = (unsigned)((total + 255) / 256);
+            if (!bwd) hipLaunchKernelGGL(dw3v_s1<false>, dim3(blocks), dim3(256), 0, st, in, w, out, C, H, W, total);
+            else hipLaunchKernelGGL(dw3v_s1<true>, dim3(blocks), dim3(256), 0, st, in, w, out, C, H, W, total);
+            return launch_status();
+        }
+        if (stride == 2 && (W & 1) == 0 && (H & 1) == 0 && (Wo & 7) == 0) {
+            if (!bwd) {
+                const long total = planes * Ho * (Wo >> 3);
+                hipLaunchKernelGGL(dw3v_s2_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, w, out, C, H,
+                                   W, Ho, Wo, total);
+            } else {
+                const long total = planes * H * (W >> 3);
+                hipLaunchKernelGGL(dw3v_s2_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, w, out, C, H,
+                                   W, Ho, Wo, total);
+            }
+            return launch_status();
+        }
+    }
     const int work = bwd ? H * W : Ho * Wo;
     int bx = (work + 255) / 256;
     if (bx > 64) bx = 64;

@@ -334,7 +334,7 @@ def test_reflect_pad1(device, dtype, shape):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("stride", [1, 2])
-@pytest.mark.parametrize("shape", [(2, 8, 24, 40), (1, 3, 7, 9), (2, 4, 1, 5)])
+@pytest.mark.parametrize("shape", [(2, 8, 24, 40), (1, 3, 7, 9), (2, 4, 1, 5), (2, 4, 16, 32), (1, 3, 6, 48), (2, 2, 2, 16)])
 def test_dwconv3x3(device, dtype, stride, shape):
     import torch.nn.functional as F
     from ppeadepth import ops
