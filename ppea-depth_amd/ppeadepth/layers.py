@@ -55,7 +55,11 @@ def transformation_from_parameters(axisangle, translation, invert=False):
 
 
 def upsample(x):
-    """layers.py:204-207."""
+    """layers.py:204-207.  Nearest-neighbour copy: run it in the tensor's own dtype (autocast would widen a
+    bf16 activation to fp32 here and every consumer down to the next conv would move twice the bytes)."""
+    if x.is_cuda and x.dtype == torch.bfloat16:
+        with torch.autocast("cuda", enabled=False):
+            return F.interpolate(x, scale_factor=2, mode="nearest")
     return F.interpolate(x, scale_factor=2, mode="nearest")
 
 
