@@ -16,10 +16,19 @@ B_GLOBAL, H, W = 2, 64, 96
 
 
 def _patch_rng():
+    """Deterministic draws (no DropPath, no matching augmentation, no tie-break noise).  Returns the originals:
+    the parent process must restore them, later tests in the same process draw through the same module."""
     from ppeadepth import rng
+    saved = (rng.bernoulli_keep, rng.aug_draws, rng.randn_like_cpu_order)
     rng.bernoulli_keep = lambda batch, keep, like: torch.ones(batch, 1, 1, 1, device=like.device, dtype=like.dtype)
     rng.aug_draws = lambda batch, device: torch.full((batch,), 0.9, device=device)
     rng.randn_like_cpu_order = lambda shape, device: torch.zeros(shape, device=device)
+    return saved
+
+
+def _restore_rng(saved):
+    from ppeadepth import rng
+    rng.bernoulli_keep, rng.aug_draws, rng.randn_like_cpu_order = saved
 
 
 def _build(batch):
@@ -76,10 +85,13 @@ def test_two_ranks_match_global_batch(device):
         p.join(120)
         assert p.exitcode == 0
     # single process, global batch of 2: SyncBN statistics over both ranks == plain BN over the batch
-    _patch_rng()
-    opt, model, tr, dev = _build(B_GLOBAL)
-    inputs = {k: v.to(dev) for k, v in synth.make_inputs(B_GLOBAL, H, W, smooth=True).items()}
-    outputs, _ = tr.process_batch(dict(inputs), True)
+    saved = _patch_rng()
+    try:
+        opt, model, tr, dev = _build(B_GLOBAL)
+        inputs = {k: v.to(dev) for k, v in synth.make_inputs(B_GLOBAL, H, W, smooth=True).items()}
+        outputs, _ = tr.process_batch(dict(inputs), True)
+    finally:
+        _restore_rng(saved)
     disp = outputs[("disp", 0)].detach().float().cpu()
     mono = outputs[("mono_disp", 0)].detach().float().cpu()
     # teacher path: only SyncBN layers see the batch -> the 2-rank result equals the global-batch result.
