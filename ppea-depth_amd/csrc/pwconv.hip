@@ -23,9 +23,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-constexpr int BN = 128, BK = 32;
-constexpr int A_STRIDE = 96;                    // bytes per A row in LDS (64 data + 32 pad)
+constexpr int BN = 128;
 constexpr int B_STRIDE = 256;                   // bytes per B row (128 pixels), swizzled
+// K step BK = 32 or 64 channels: the long-K, few-tile shapes of stage 2 are bound by the per-step barrier and
+// load latency, not by MFMA issue -- twice the work per step halves that overhead.
+constexpr int a_stride(int bk) { return bk == 32 ? 96 : 160; }   // bytes per A row in LDS: data + 32 (32 * odd)
 
 __device__ __forceinline__ int b_swz(int row) { return 4 * (row & 3) + 16 * ((row >> 3) & 1); }
 
@@ -40,16 +42,18 @@ __device__ __forceinline__ float dgelu_f(float x) {
 // autocast nn.GELU on the stored tensor).   EPI 2: Y = acc * GELU'(aux[n][m][p]) (data gradient through GELU).
 // TA: the matrix is given transposed, At [K][M] (m contiguous) -- its tile is staged like the X tile and the A
 // fragments come out of the transposing LDS read as well, so a data gradient uses the forward weight as is.
-template <int BM, int WM, int WN, int EPI, bool TA>
+template <int BM, int WM, int WN, int EPI, bool TA, int BK>
 __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ X,
                                                      const void* __restrict__ bias, int bias_bf16,
                                                      const uint16_t* __restrict__ aux, uint16_t* __restrict__ Y,
                                                      uint16_t* __restrict__ Y2, int M, int K, int HW) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
+    constexpr int A_STRIDE = a_stride(BK), KH = BK / 32;
     constexpr int A_BYTES = TA ? BK * B_STRIDE : BM * A_STRIDE, B_BYTES = BK * B_STRIDE;
-    constexpr int A_CH = (BM * 4 + 255) / 256;  // 16-byte chunks of the A tile per thread
-    constexpr int A_CPR = TA ? BM / 8 : 4;      // chunks per staged row: [32 k][BM m] or [BM m][32 k]
+    constexpr int A_CH = (BM * BK / 8 + 255) / 256;  // 16-byte chunks of the A tile per thread
+    constexpr int A_CPR = TA ? BM / 8 : BK / 8;      // chunks per staged row: [BK k][BM m] or [BM m][BK k]
+    constexpr int B_CH = BK * 16 / 256;              // 16-byte chunks of the X tile per thread
     constexpr int BUF = A_BYTES + B_BYTES;
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * BUF];      // double buffered: one barrier per K step
 
@@ -68,29 +72,29 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
     int a_row[A_CH], a_ch[A_CH];
 #pragma unroll
     for (int c = 0; c < A_CH; ++c) { const int idx = tid + c * 256; a_row[c] = idx / A_CPR; a_ch[c] = idx % A_CPR; }
-    int b_row[2], b_c16[2];
+    int b_row[B_CH], b_c16[B_CH];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) { const int idx = tid + c * 256; b_row[c] = idx >> 4; b_c16[c] = idx & 15; }
+    for (int c = 0; c < B_CH; ++c) { const int idx = tid + c * 256; b_row[c] = idx >> 4; b_c16[c] = idx & 15; }
 
-    uint4 a_reg[A_CH], b_reg[2];
+    uint4 a_reg[A_CH], b_reg[B_CH];
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int c = 0; c < A_CH; ++c) {
             if constexpr (TA) {
                 const int m = m0 + a_ch[c] * 8;
-                a_reg[c] = (m < M && a_row[c] < BK) ? *reinterpret_cast<const uint4*>(A + (long)(k0 + a_row[c]) * M + m)
-                                                    : make_uint4(0, 0, 0, 0);
+                a_reg[c] = (m < M && a_row[c] < BK && k0 + a_row[c] < K)
+                               ? *reinterpret_cast<const uint4*>(A + (long)(k0 + a_row[c]) * M + m) : make_uint4(0, 0, 0, 0);
             } else {
                 const int m = m0 + a_row[c];
-                a_reg[c] = (m < M && a_row[c] < BM)
+                a_reg[c] = (m < M && a_row[c] < BM && k0 + a_ch[c] * 8 < K)
                                ? *reinterpret_cast<const uint4*>(A + (long)m * K + k0 + a_ch[c] * 8) : make_uint4(0, 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < B_CH; ++c) {
             const int p = p0 + b_c16[c] * 8;
-            b_reg[c] = (p < HW) ? *reinterpret_cast<const uint4*>(Xn + (long)(k0 + b_row[c]) * HW + p)
-                                : make_uint4(0, 0, 0, 0);
+            b_reg[c] = (p < HW && k0 + b_row[c] < K) ? *reinterpret_cast<const uint4*>(Xn + (long)(k0 + b_row[c]) * HW + p)
+                                                     : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_tiles = [&](uint8_t* As) {
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
             }
         }
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < B_CH; ++c) {
             const int s = b_swz(b_row[c]);
             uint8_t* rowp = Bs + b_row[c] * B_STRIDE;
             *reinterpret_cast<uint2*>(rowp + (((2 * b_c16[c]) ^ s) << 3)) = make_uint2(b_reg[c].x, b_reg[c].y);
@@ -132,36 +136,39 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
         const bool more = k0 + BK < K;
         if (more) load_tiles(k0 + BK);            // in flight while the MFMAs of this step run
         const uint8_t* buf = lds + cur * BUF;
-        bf16x8 af[MT], bfr[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            if constexpr (TA) {
-                const int chunk = (((wm * TM + 16 * i) >> 2) + pp) ^ b_swz(b_rowi);
-                const uint8_t* ap = buf + a_off + (chunk << 3);
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap + 4 * B_STRIDE));
+        for (int h = 0; h < KH; ++h) {                    // 32-wide halves of the K step
+            bf16x8 af[MT], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (TA) {
+                    const int chunk = (((wm * TM + 16 * i) >> 2) + pp) ^ b_swz(b_rowi);
+                    const uint8_t* ap = buf + a_off + h * 32 * B_STRIDE + (chunk << 3);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap + 4 * B_STRIDE));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    af[i] = __builtin_bit_cast(bf16x8, both);
+                } else {
+                    af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + a_off + i * 16 * A_STRIDE + h * 64));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int chunk = (((wn * TN + 16 * j) >> 2) + pp) ^ b_s;
+                const uint8_t* bp = buf + b_off + h * 32 * B_STRIDE + (chunk << 3);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp + 4 * B_STRIDE));
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                af[i] = __builtin_bit_cast(bf16x8, both);
-            } else {
-                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + a_off + i * 16 * A_STRIDE));
+                bfr[j] = __builtin_bit_cast(bf16x8, both);
             }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int chunk = (((wn * TN + 16 * j) >> 2) + pp) ^ b_s;
-            const uint8_t* bp = buf + b_off + (chunk << 3);
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp + 4 * B_STRIDE));
-            typedef __attribute__((ext_vector_type(8))) short s16x8;
-            const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            bfr[j] = __builtin_bit_cast(bf16x8, both);
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         if (more) store_tiles(lds + (cur ^ 1) * BUF);   // the other buffer was last read one barrier ago
         __syncthreads();
         cur ^= 1;
@@ -200,14 +207,17 @@ int launch_pw(const void* A, const void* X, const void* bias, int bias_bf16, con
               int M, int K, int HW, hipStream_t st) {
     const int nb = (HW + BN - 1) / BN;
     const long blocks128 = (long)nb * ((M + 127) / 128) * B;
-#define PW_LAUNCH(BM_, WM_, WN_)                                                                                  \
-    hipLaunchKernelGGL((pwconv_kernel<BM_, WM_, WN_, EPI, TA>), dim3(nb, (M + BM_ - 1) / BM_, B), dim3(256), 0, st, \
+#define PW_LAUNCH(BM_, WM_, WN_, BK_)                                                                                 \
+    hipLaunchKernelGGL((pwconv_kernel<BM_, WM_, WN_, EPI, TA, BK_>), dim3(nb, (M + BM_ - 1) / BM_, B), dim3(256), 0, st, \
                        (const uint16_t*)A, (const uint16_t*)X, bias, bias_bf16, (const uint16_t*)aux, (uint16_t*)Y, \
                        (uint16_t*)Y2, M, K, HW)
     const long blocks64 = (long)nb * ((M + 63) / 64) * B;
-    if (M >= 128 && blocks128 >= 512) PW_LAUNCH(128, 2, 2);
-    else if (M > 32 && blocks64 >= 256) PW_LAUNCH(64, 2, 2);
-    else PW_LAUNCH(32, 1, 4);            // few tiles: more, smaller workgroups (one per CU at least)
+    // 64 channels per step only where it pays (measured): long contraction AND too few tiles to hide the per-step
+    // latency by occupancy; with plenty of tiles the smaller LDS footprint (more workgroups per CU) wins.
+    const bool deep = K >= 512;
+    if (M >= 128 && blocks128 >= 512) PW_LAUNCH(128, 2, 2, 32);
+    else if (M > 32 && blocks64 >= 256) { if (deep) PW_LAUNCH(64, 2, 2, 64); else PW_LAUNCH(64, 2, 2, 32); }
+    else { if (deep) PW_LAUNCH(32, 1, 4, 64); else PW_LAUNCH(32, 1, 4, 32); }   // few tiles: smaller workgroups
 #undef PW_LAUNCH
     return launch_status();
 }
@@ -220,7 +230,7 @@ extern "C" {
 // Requirements of the fast path: K % 32 == 0, HW % 8 == 0 (else PPEA_ERR_UNSUPPORTED).
 int ppea_pwconv_bf16(const void* A, const void* X, const float* bias, void* Y, int B, int M, int K, int HW,
                      void* stream) {
-    if (B <= 0 || M <= 0 || K <= 0 || HW <= 0 || (K % BK) != 0 || (HW % 8) != 0 || B > 65535)
+    if (B <= 0 || M <= 0 || K <= 0 || HW <= 0 || (K % 32) != 0 || (HW % 8) != 0 || B > 65535)
         return PPEA_ERR_UNSUPPORTED;
     return launch_pw<0, false>(A, X, bias, 0, nullptr, Y, nullptr, B, M, K, HW, (hipStream_t)stream);
 }
@@ -230,7 +240,7 @@ int ppea_pwconv_bf16(const void* A, const void* X, const float* bias, void* Y, i
 // `bias` is fp32 or, with bias_bf16 != 0, bf16.  a_transposed != 0: A is given as At [K][M] (M % 8 == 0).
 int ppea_pwconv_ex_bf16(const void* A, const void* X, const void* bias, int bias_bf16, int epi, const void* aux,
                         void* Y, void* Y2, int B, int M, int K, int HW, int a_transposed, void* stream) {
-    if (B <= 0 || M <= 0 || K <= 0 || HW <= 0 || (K % BK) != 0 || (HW % 8) != 0 || B > 65535)
+    if (B <= 0 || M <= 0 || K <= 0 || HW <= 0 || (K % 32) != 0 || (HW % 8) != 0 || B > 65535)
         return PPEA_ERR_UNSUPPORTED;
     if (a_transposed && (M % 8) != 0) return PPEA_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
