@@ -260,6 +260,14 @@ int ppea_cost_volume_reduce_f32(const float* cost, const float* bins, float* cos
                                 float* confidence, int64_t* argmin, float* lowest,
                                 int B, int D, int h, int w, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimizer step (trainer.py:350, torch.optim.Adam with the reference's defaults) over ONE flat fp32 buffer
+ * holding every trainable tensor: p, g, m, v fp32 [n]; w16 (may be NULL) = bf16 working copy of p[0, n_lo);
+ * state = device float[2] {step t >= 1, learning rate}.
+ * ---------------------------------------------------------------------------------------- */
+int ppea_adam_flat_f32(float* p, const float* g, float* m, float* v, void* w16, long n, long n_lo,
+                       const float* state, float beta1, float beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,28 +61,29 @@ class FlatGrads:
     `targets[i].grad` is a view into the buffer; `gather(sources)` fills it from the model parameters'
     freshly produced gradients (bf16 or fp32) with ONE multi-tensor copy."""
 
-    def __init__(self, targets, n_chunks=4):
+    def __init__(self, targets, n_chunks=4, align=1):
         self.targets = list(targets)
         device = self.targets[0].device
-        self.numel = sum(p.numel() for p in self.targets)
-        self.flat = torch.zeros(self.numel, device=device, dtype=torch.float32)
-        off = 0
-        self.views = []
+        # every tensor starts at a multiple of `align` elements (flat optimizer: parameter views keep the
+        # 256-byte alignment the GEMM / conv kernels expect of a weight pointer)
+        self.offsets, off = [], 0
         for p in self.targets:
-            n = p.numel()
-            v = self.flat[off:off + n].view_as(p)
+            self.offsets.append(off)
+            off += -(-p.numel() // align) * align
+        self.numel = off
+        self.flat = torch.zeros(self.numel, device=device, dtype=torch.float32)
+        self.views = []
+        for p, off in zip(self.targets, self.offsets):
+            v = self.flat[off:off + p.numel()].view_as(p)
             self.views.append(v)
             p.grad = v
-            off += n
         n_chunks = max(1, min(n_chunks, len(self.targets)))
         target = self.numel / n_chunks                     # chunk boundaries on tensor boundaries
-        self.bounds, acc = [0], 0
-        for p in self.targets:
-            acc += p.numel()
-            if acc >= target * len(self.bounds) and len(self.bounds) < n_chunks:
-                self.bounds.append(acc)
-        if self.bounds[-1] != self.numel:
-            self.bounds.append(self.numel)
+        self.bounds = [0]
+        for off in self.offsets[1:]:
+            if off >= target * len(self.bounds) and len(self.bounds) < n_chunks:
+                self.bounds.append(off)
+        self.bounds.append(self.numel)
         self.comm_stream = torch.cuda.Stream(device) if device.type == "cuda" else None
 
     def zero(self):
@@ -90,14 +91,15 @@ class FlatGrads:
 
     def gather(self, sources):
         """views[i] <- sources[i].grad (zero where a parameter received no gradient)."""
-        dst, src = [], []
+        groups = {}                    # one multi-tensor copy per source dtype (mixed lists take the slow path)
         for v, p in zip(self.views, sources):
             if p.grad is None:
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
+                dst, src = groups.setdefault(p.grad.dtype, ([], []))
                 dst.append(v)
                 src.append(p.grad)
-        if dst:
+        for dst, src in groups.values():
             torch._foreach_copy_(dst, src)
         for t, v in zip(self.targets, self.views):
             t.grad = v
@@ -122,6 +124,9 @@ class FlatGrads:
                 chunk.mul_(1.0 / w)
 
 
+FLAT_ADAM = True     # one-launch Adam over a flat parameter buffer (GPU, fused path)
+
+
 class TrainEngine:
     """process_batch -> backward -> gradient exchange -> Adam step (trainer.py:345-351)."""
 
@@ -142,13 +147,27 @@ class TrainEngine:
         self.opt_params = [self.masters.get(id(p), p) for p in self.params] if self.masters else self.params
         self._lo = [p for p in self.params if self.masters and id(p) in self.masters]
         self._hi = [self.masters[id(p)] for p in self._lo]
-        self.flat = FlatGrads(self.opt_params, n_chunks) if collectives_on() else None
+        self.flat_adam = bool(fused_adam and on_gpu and FLAT_ADAM)
+        if self.flat_adam:
+            # bf16-backed tensors first: their working copies mirror the head of the flat fp32 buffer
+            order = [i for i, p in enumerate(self.params) if self.masters and id(p) in self.masters] + \
+                    [i for i, p in enumerate(self.params) if not (self.masters and id(p) in self.masters)]
+            self.params = [self.params[i] for i in order]
+            self.opt_params = [self.opt_params[i] for i in order]
+            self._lo = [p for p in self.params if self.masters and id(p) in self.masters]
+            self._hi = [self.masters[id(p)] for p in self._lo]
+        self.flat = FlatGrads(self.opt_params, n_chunks, align=128 if self.flat_adam else 1) \
+            if (collectives_on() or self.flat_adam) else None
         if self.flat is None and self._lo:
             self._hi_grads = [torch.zeros_like(m) for m in self._hi]
             for m, g in zip(self._hi, self._hi_grads):
                 m.grad = g
+        # torch's optimizer object always exists (learning-rate schedule, param_groups API); with the flat layout
+        # its step() is replaced by one launch of ppea_adam_flat_f32 over the buffers built below
         self.optimizer = torch.optim.Adam(self.opt_params, lr, fused=True, capturable=on_gpu) if fused_adam else \
             torch.optim.Adam(self.opt_params, lr, foreach=True)
+        if self.flat_adam:
+            self._build_flat_state()
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, trainer.opt.scheduler_step_size, 0.1)
         self.graph = None
         self.static_inputs = None
@@ -191,6 +210,45 @@ class TrainEngine:
                 elif p.dtype == torch.bfloat16:
                     sd[name] = p.detach().float()
         return sd
+
+    # ---- flat optimizer state -------------------------------------------------------------------------
+    # Every tensor Adam updates becomes a view into ONE fp32 buffer (bf16-backed ones first), their bf16 working
+    # copies views into one bf16 buffer with the same element order: parameter update, moment update and the
+    # master -> bf16 refresh are a single streaming kernel instead of ~90 multi-tensor launches.
+    def _build_flat_state(self):
+        dev = self.opt_params[0].device
+        n = self.flat.numel
+        self.P = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.M = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.V = torch.zeros(n, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for t, off in zip(self.opt_params, self.flat.offsets):
+                view = self.P[off:off + t.numel()].view_as(t)
+                view.copy_(t)
+                t.data = view
+            # the bf16-backed tensors come first, so their (aligned) offsets are valid in the bf16 buffer as well
+            n_lo_t = len(self._lo)
+            self.n_lo = (self.flat.offsets[n_lo_t] if n_lo_t < len(self.opt_params) else n) if n_lo_t else 0
+            self.W16 = torch.zeros(max(self.n_lo, 1), device=dev, dtype=torch.bfloat16)
+            for p, off in zip(self._lo, self.flat.offsets):
+                view = self.W16[off:off + p.numel()].view_as(p)
+                view.copy_(p)
+                p.data = view
+        self.adam_state = torch.tensor([0.0, float(self.optimizer.param_groups[0]["lr"])], device=dev)
+
+    def _flat_adam_step(self):
+        from ._abi import call, ptr, stream_ptr
+        g = self.optimizer.param_groups[0]
+        with torch.no_grad():
+            self.adam_state[0] += 1
+        call("ppea_adam_flat_f32", ptr(self.P), ptr(self.flat.flat), ptr(self.M), ptr(self.V),
+             ptr(self.W16) if self.n_lo else None, self.flat.numel, self.n_lo, ptr(self.adam_state),
+             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), stream_ptr())
+
+    def sync_lr(self):
+        """Push the optimizer's (scheduled) learning rate into the device scalar the step kernel reads."""
+        if self.flat_adam:
+            self.adam_state[1].fill_(float(self.optimizer.param_groups[0]["lr"]))
 
     # ---- whole-step hipGraph -------------------------------------------------------------------------
     # ~10k kernel launches per step make the eager step host-bound (Python + dispatcher ~15 us per
@@ -235,17 +293,20 @@ class TrainEngine:
         for p in self.params:
             p.grad = None              # autograd then hands each gradient over without an accumulate kernel
         losses["loss"].backward()
-        if self.flat is not None:      # several ranks: pack -> few large all-reduces -> Adam on the views
+        if self.flat is not None:      # pack -> (several ranks: few large all-reduces) -> Adam on the flat buffer
             self.flat.gather(self.params)
             self.flat.all_reduce_mean()
-        elif self._lo:                 # one rank, bf16 working weights: bf16 grads -> fp32 master grads
+        elif self._lo:                 # bf16 working weights: bf16 grads -> fp32 master grads
             with torch.no_grad():
                 torch._foreach_copy_(self._hi_grads, [p.grad if p.grad is not None else torch.zeros_like(p)
                                                       for p in self._lo])
-        self.optimizer.step()
-        if self._lo:
-            with torch.no_grad():
-                torch._foreach_copy_(self._lo, self._hi)  # masters -> bf16 working weights
+        if self.flat_adam:
+            self._flat_adam_step()     # also refreshes the bf16 working weights
+        else:
+            self.optimizer.step()
+            if self._lo:
+                with torch.no_grad():
+                    torch._foreach_copy_(self._lo, self._hi)  # masters -> bf16 working weights
         return outputs, losses
 
     def step(self, inputs):

@@ -433,3 +433,27 @@ def test_adapters_mfma(device, kind, B, C, H, W):
         assert a.grad.dtype == a.dtype
         err = (a.grad.float().cpu() - r.grad).abs().max()
         assert err <= tol * r.grad.abs().max(), (name, float(err), float(r.grad.abs().max()))
+
+
+def test_adam_flat_matches_torch_adam(device):
+    """One-launch Adam over a flat buffer == torch.optim.Adam (reference defaults) step for step; the bf16 working
+    copy of the head of the buffer is the rounded master."""
+    from ppeadepth._abi import call, ptr, stream_ptr
+    g = _g(5)
+    n, n_lo = 10007, 4099
+    p0 = torch.randn(n, generator=g)
+    ref = p0.clone().to(device).requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    P = p0.clone().to(device)
+    M, V = torch.zeros_like(P), torch.zeros_like(P)
+    W16 = torch.empty(n_lo, device=device, dtype=torch.bfloat16)
+    state = torch.tensor([0.0, 1e-3], device=device)
+    for step in range(4):
+        grad = (torch.randn(n, generator=g) * (10.0 ** (step - 2))).to(device)
+        ref.grad = grad.clone()
+        opt.step()
+        state[0] += 1
+        call("ppea_adam_flat_f32", ptr(P), ptr(grad), ptr(M), ptr(V), ptr(W16), n, n_lo, ptr(state), 0.9, 0.999, 1e-8,
+             stream_ptr())
+        assert (P - ref.detach()).abs().max() <= 2e-7 * ref.detach().abs().max() + 1e-9, step
+    assert torch.equal(W16, P[:n_lo].bfloat16())
