@@ -145,6 +145,16 @@ int ppea_bn_stats_bf16(const void* z, float* partial, int N, int C, int HW, void
 int ppea_bn_finalize_f32(const float* partial, int N, int C, int HW, float eps, float momentum,
                          float* mean, float* var, float* invstd, float* running_mean,
                          float* running_var, void* stream);
+/* Small channels (N*HW <= 16384 elements, HW % 8 == 0, C >= 64): statistics (resp. backward sums) final in ONE
+ * launch, one wave per channel over all N planes; PPEA_ERR_UNSUPPORTED otherwise (use the two-launch forms). */
+int ppea_bn_stats_final_f32(const void* z, int N, int C, int HW, float eps, float momentum, float* mean, float* var,
+                            float* invstd, float* running_mean, float* running_var, void* stream);
+int ppea_bn_stats_final_bf16(const void* z, int N, int C, int HW, float eps, float momentum, float* mean, float* var,
+                             float* invstd, float* running_mean, float* running_var, void* stream);
+int ppea_bn_bwd_reduce_final_f32(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                                 const float* mask, float* sums, int act, int N, int C, int HW, void* stream);
+int ppea_bn_bwd_reduce_final_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                                  const float* mask, float* sums, int act, int N, int C, int HW, void* stream);
 /* SyncBatchNorm across ranks (one packed all-gather per BN forward, trainer.py:215-222 + get_bn rka.py:176-180):
  * local statistics in wire layout packed[2C+1] = mean[C] | biased var[C] | count, and the Chan combine of the
  * gathered [world][2C+1] table into mean / invstd (running statistics updated unless running_mean is NULL). */

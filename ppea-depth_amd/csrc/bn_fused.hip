@@ -407,6 +407,102 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_wave(const T* __restrict__ 
     }
 }
 
+// ---- small channels (N*HW <= 16384 elements): one WORKGROUP per CHANNEL covers all N planes, so the statistics
+// are final when it is done -- no partial buffer, no finalize launch (stages 2 and 3 of the trunk: 20 of
+// the 24 blocks of each encoder).
+constexpr int CH_VECS = 8;                   // 16-byte vectors per thread: N * HW <= 256 * 8 * 8 = 16384 elements
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_stats_channel(const T* __restrict__ z, int N, int C, int HW, float eps,
+                                                        float momentum, float* __restrict__ mean_out,
+                                                        float* __restrict__ var_out, float* __restrict__ invstd_out,
+                                                        float* __restrict__ running_mean,
+                                                        float* __restrict__ running_var) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const int hv = HW / V, total = N * hv;              // vectors per plane / per channel
+    // every load of the channel is issued before the first use: one memory latency for the whole pass, and
+    // the values stay in registers for the second (centred) pass
+    float x[CH_VECS][V];
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j < total) {
+            const int n = j / hv, i = j - n * hv;
+            ld8<T>(z + ((long)n * C + c) * HW + i * V, x[u]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) x[u][k] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u)
+#pragma unroll
+        for (int k = 0; k < V; ++k) s += x[u][k];
+    const float cnt = (float)N * (float)HW;
+    const float mean = block_sum(s, red) / cnt;
+    float m2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u)
+        if (threadIdx.x + u * TPB < total) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) m2 += (x[u][k] - mean) * (x[u][k] - mean);
+        }
+    m2 = block_sum(m2, red);
+    if (threadIdx.x == 0) {
+        const float var = m2 / cnt;
+        mean_out[c] = mean;
+        var_out[c] = var;
+        invstd_out[c] = rsqrtf(var + eps);
+        if (running_mean != nullptr) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / fmaxf(cnt - 1.f, 1.f));
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_channel(const T* __restrict__ dy, const T* __restrict__ z1,
+                                                             const T* __restrict__ z2, Branch b1, Branch b2,
+                                                             const float* __restrict__ mask, float* __restrict__ sums,
+                                                             int act, int N, int C, int HW) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const int hv = HW / V, total = N * hv;
+    const float is1 = b1.invstd[c], mu1 = b1.mean[c];
+    const float a1 = b1.gamma[c] * is1, o1 = b1.beta[c] - mu1 * a1;
+    float is2 = 0.f, mu2 = 0.f, a2 = 0.f, o2 = 0.f;
+    if (z2 != nullptr) { is2 = b2.invstd[c]; mu2 = b2.mean[c]; a2 = b2.gamma[c] * is2; o2 = b2.beta[c] - mu2 * a2; }
+    float sg = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+    for (int u = 0; u < CH_VECS; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j >= total) break;
+        const int n = j / hv, i = j - n * hv;
+        const float m = (mask != nullptr) ? mask[n] : 1.f;
+        const long base = ((long)n * C + c) * HW + i * V;
+        float x1[V], x2[V], d[V];
+        ld8<T>(z1 + base, x1);
+        if (z2 != nullptr) ld8<T>(z2 + base, x2);
+        ld8<T>(dy + base, d);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float u2 = a1 * x1[k] + o1;
+            float xx2 = 0.f;
+            if (z2 != nullptr) { xx2 = x2[k]; u2 += a2 * xx2 + o2; }
+            const float g = d[k] * m * act_bwd(u2, act);
+            sg += g;
+            s1 += g * (x1[k] - mu1) * is1;
+            s2 += g * (xx2 - mu2) * is2;
+        }
+    }
+    sg = block_sum(sg, red); s1 = block_sum(s1, red); s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) { sums[c] = sg; sums[C + c] = s1; sums[2 * C + c] = s2; }
+}
+
+constexpr long CHANNEL_ELEMS = 16384;       // N * HW up to here: the wave-per-channel kernels
+
 // ---- flat element-wise passes (HW % 8 == 0): 8 elements per thread, channel looked up per thread -------
 template <typename T>
 __global__ __launch_bounds__(TPB) void bn_apply_flat(const T* __restrict__ z1, const T* __restrict__ z2, Branch b1,
@@ -554,6 +650,24 @@ int bwd_apply_impl(const void* dy, const void* z1, const void* z2, const float* 
 
 }  // namespace
 
+template <typename T>
+int stats_final_impl(const void* z, int N, int C, int HW, float eps, float momentum, float* mean, float* var,
+                     float* invstd, float* running_mean, float* running_var, void* stream) {
+    if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS) return PPEA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_stats_channel<T>, dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream,
+                       (const T*)z, N, C, HW, eps, momentum, mean, var, invstd, running_mean, running_var);
+    return launch_status();
+}
+template <typename T>
+int bwd_reduce_final_impl(const void* dy, const void* z1, const void* z2, const float* const* st, const float* mask,
+                          float* sums, int act, int N, int C, int HW, void* stream) {
+    if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS) return PPEA_ERR_UNSUPPORTED;
+    Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
+    hipLaunchKernelGGL(bn_bwd_reduce_channel<T>, dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream,
+                       (const T*)dy, (const T*)z1, (const T*)z2, b1, b2, mask, sums, act, N, C, HW);
+    return launch_status();
+}
+
 extern "C" {
 
 // stats[8] = {mean1, invstd1, gamma1, beta1, mean2, invstd2, gamma2, beta2} (branch 2 NULL when z2 is NULL)
@@ -569,6 +683,22 @@ int ppea_bn_finalize_f32(const float* partial, int N, int C, int HW, float eps, 
     hipLaunchKernelGGL(bn_finalize, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, N, C, HW, eps,
                        momentum, mean, var, invstd, running_mean, running_var);
     return launch_status();
+}
+int ppea_bn_stats_final_f32(const void* z, int N, int C, int HW, float eps, float momentum, float* mean, float* var,
+                            float* invstd, float* running_mean, float* running_var, void* stream) {
+    return stats_final_impl<float>(z, N, C, HW, eps, momentum, mean, var, invstd, running_mean, running_var, stream);
+}
+int ppea_bn_stats_final_bf16(const void* z, int N, int C, int HW, float eps, float momentum, float* mean, float* var,
+                             float* invstd, float* running_mean, float* running_var, void* stream) {
+    return stats_final_impl<uint16_t>(z, N, C, HW, eps, momentum, mean, var, invstd, running_mean, running_var, stream);
+}
+int ppea_bn_bwd_reduce_final_f32(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                                 const float* mask, float* sums, int act, int N, int C, int HW, void* stream) {
+    return bwd_reduce_final_impl<float>(dy, z1, z2, stats, mask, sums, act, N, C, HW, stream);
+}
+int ppea_bn_bwd_reduce_final_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                                  const float* mask, float* sums, int act, int N, int C, int HW, void* stream) {
+    return bwd_reduce_final_impl<uint16_t>(dy, z1, z2, stats, mask, sums, act, N, C, HW, stream);
 }
 int ppea_bn_finalize_packed_f32(const float* partial, int N, int C, int HW, float* packed, void* stream) {
     if (N <= 0 || C <= 0 || HW <= 0) return PPEA_ERR_UNSUPPORTED;

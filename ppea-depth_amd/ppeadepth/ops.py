@@ -371,8 +371,15 @@ def bn_batch_stats(z, eps, momentum, running_mean=None, running_var=None):
     N, C = z.shape[0], z.shape[1]
     HW = z.numel() // (N * C)
     dev = z.device
-    partial = torch.empty(C * N * 2, device=dev, dtype=_F32)
     out = torch.empty(3, C, device=dev, dtype=_F32)
+    err = getattr(_abi.lib, f"ppea_bn_stats_final_{_suffix(z)}")(
+        ptr(z), N, C, HW, float(eps), float(momentum), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(running_mean),
+        ptr(running_var), stream_ptr())
+    if err == 0:                            # small channels: statistics final in one launch
+        return out[0], out[1], out[2]
+    if err != -1:
+        _abi.check(err, "ppea_bn_stats_final")
+    partial = torch.empty(C * N * 2, device=dev, dtype=_F32)
     call(f"ppea_bn_stats_{_suffix(z)}", ptr(z), ptr(partial), N, C, HW, stream_ptr())
     call("ppea_bn_finalize_f32", ptr(partial), N, C, HW, float(eps), float(momentum), ptr(out[0]), ptr(out[1]),
          ptr(out[2]), ptr(running_mean), ptr(running_var), stream_ptr())
@@ -433,12 +440,17 @@ class _BnAct(torch.autograd.Function):
         dy = dy.contiguous().to(z1.dtype)
         dev = z1.device
         st = _stats_array((mean1, invstd1, g1f, b1f, mean2, invstd2, g2f, b2f))
-        partial = torch.empty(C * N * 3, device=dev, dtype=_F32)
         sums = torch.empty(3, C, device=dev, dtype=_F32)
         sfx = _suffix(z1)
-        call(f"ppea_bn_bwd_reduce_{sfx}", ptr(dy), ptr(z1), ptr(z2), st, ptr(maskf), ptr(partial), ctx.act, N, C,
-             HW, stream_ptr())
-        call("ppea_bn_bwd_finalize_f32", ptr(partial), N, C, ptr(sums), stream_ptr())
+        err = getattr(_abi.lib, f"ppea_bn_bwd_reduce_final_{sfx}")(
+            ptr(dy), ptr(z1), ptr(z2), st, ptr(maskf), ptr(sums), ctx.act, N, C, HW, stream_ptr())
+        if err == -1:                       # large planes: per-plane partials + finalize
+            partial = torch.empty(C * N * 3, device=dev, dtype=_F32)
+            call(f"ppea_bn_bwd_reduce_{sfx}", ptr(dy), ptr(z1), ptr(z2), st, ptr(maskf), ptr(partial), ctx.act, N, C,
+                 HW, stream_ptr())
+            call("ppea_bn_bwd_finalize_f32", ptr(partial), N, C, ptr(sums), stream_ptr())
+        elif err != 0:
+            _abi.check(err, "ppea_bn_bwd_reduce_final")
         if ctx.group is not None:                      # SyncBN: global sums (count is already global)
             import torch.distributed as dist
             dist.all_reduce(sums, group=ctx.group[0])

@@ -265,7 +265,7 @@ def test_cost_volume_golden(device, golden):
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("two,act,res", [(False, 0, False), (False, 1, False), (True, 1, False), (False, 2, False),
                                          (False, 0, True)])
-@pytest.mark.parametrize("shape", [(3, 8, 12, 40), (2, 5, 7, 9), (2, 4, 48, 160)])
+@pytest.mark.parametrize("shape", [(3, 8, 12, 40), (2, 5, 7, 9), (2, 4, 48, 160), (5, 64, 12, 40), (3, 130, 6, 20)])
 def test_fused_bn_act(device, dtype, two, act, res, shape):
     """act(BN_a(z1) [+ BN_b(z2)]) * mask + r1 + s*r2 (training-mode batch statistics), forward, running
     statistics and all gradients against the oracle composite."""
@@ -278,7 +278,7 @@ def test_fused_bn_act(device, dtype, two, act, res, shape):
     z2 = (torch.randn(shape, generator=g) * 0.7 - 0.2).to(dt)
     g1, b1 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
     g2, b2 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
-    mask = torch.tensor([0.0, 1.4, 1.4][:N])
+    mask = torch.tensor(([0.0] + [1.4] * N)[:N])
     r1 = torch.randn(shape, generator=g).to(dt)
     r2 = torch.randn(shape, generator=g).to(dt)
     go = torch.randn(shape, generator=g).to(dt)
