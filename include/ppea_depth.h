@@ -271,6 +271,17 @@ int ppea_cost_volume_reduce_f32(const float* cost, const float* bins, float* cos
                                 int B, int D, int h, int w, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Bias + ELU of the decoders' ConvBlock (layers.py:103-116), NCHW: y = elu(z + bias[c]); backward dz = dy * elu'
+ * (from the saved OUTPUT: elu' = 1 for y > 0 else y + 1) and partial[N*C][chunks] = per-plane-chunk sums of dz
+ * (chunks = ppea_bias_elu_chunks(N, C, HW)); the bias gradient is their sum over N and chunks.
+ * ---------------------------------------------------------------------------------------- */
+int ppea_bias_elu_chunks(int N, int C, int HW);
+int ppea_bias_elu_fwd_f32(const void* z, const void* bias, int bias_bf16, void* y, int N, int C, int HW, void* stream);
+int ppea_bias_elu_fwd_bf16(const void* z, const void* bias, int bias_bf16, void* y, int N, int C, int HW, void* stream);
+int ppea_bias_elu_bwd_f32(const void* dy, const void* y, void* dz, float* partial, int N, int C, int HW, void* stream);
+int ppea_bias_elu_bwd_bf16(const void* dy, const void* y, void* dz, float* partial, int N, int C, int HW, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimizer step (trainer.py:350, torch.optim.Adam with the reference's defaults) over ONE flat fp32 buffer
  * holding every trainable tensor: p, g, m, v fp32 [n]; w16 (may be NULL) = bf16 working copy of p[0, n_lo);
  * state = device float[2] {step t >= 1, learning rate}.

@@ -37,6 +37,11 @@ SIGNATURES = {
     "ppea_pwgrad_workspace_bytes": [_i, _i, _i, _i],
     "ppea_pwgrad_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ppea_pwgrad_ex_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "ppea_bias_elu_chunks": [_i, _i, _i],
+    "ppea_bias_elu_fwd_f32": [_vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "ppea_bias_elu_fwd_bf16": [_vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "ppea_bias_elu_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ppea_bias_elu_bwd_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ppea_adam_flat_f32": [_vp, _vp, _vp, _vp, _vp, ctypes.c_long, ctypes.c_long, _vp, _f, _f, _f, _vp],
     "ppea_tapsum_fwd_bf16": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_tapsum_bwd_bf16": [_vp, _vp, _i, _i, _i, _i, _vp],

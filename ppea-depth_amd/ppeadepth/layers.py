@@ -9,6 +9,9 @@ import torch.nn.functional as F
 from . import ops
 
 
+FUSE_BIAS_ELU = True
+
+
 def disp_to_depth(disp, min_depth, max_depth):
     """layers.py:14-23."""
     min_disp = 1.0 / max_depth
@@ -87,6 +90,13 @@ class ConvBlock(nn.Module):
         self.nonlin = nn.ELU(inplace=True)
 
     def forward(self, x):
+        c = self.conv
+        if FUSE_BIAS_ELU and x.is_cuda and c.use_refl and c.conv.bias is not None:
+            # conv without bias, then bias + ELU in one pass whose backward also yields the bias gradient
+            z = F.conv2d(ops.reflect_pad1(x), c.conv.weight, None)
+            if z.dtype in (torch.float32, torch.bfloat16):
+                return ops.bias_elu(z, c.conv.bias)
+            return self.nonlin(z + c.conv.bias.view(1, -1, 1, 1))
         return self.nonlin(self.conv(x))
 
 

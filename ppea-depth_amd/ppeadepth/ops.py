@@ -476,6 +476,40 @@ def bn_act_apply(z1, g1, b1, mean1, invstd1, z2=None, g2=None, b2=None, mean2=No
 
 
 # ---------------------------------------------------------------------------------------------
+# A12 glue: bias + ELU of ConvBlock                                         layers.py:103-116
+# ---------------------------------------------------------------------------------------------
+class _BiasElu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, bias):
+        z = z.contiguous()
+        N, C = z.shape[0], z.shape[1]
+        HW = z.numel() // (N * C)
+        y = torch.empty_like(z)
+        bp, bflag = _bias_arg(bias.detach().contiguous())
+        call(f"ppea_bias_elu_fwd_{_suffix(z)}", ptr(z), bp, bflag, ptr(y), N, C, HW, stream_ptr())
+        ctx.save_for_backward(y)
+        ctx.bdt = bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        N, C = y.shape[0], y.shape[1]
+        HW = y.numel() // (N * C)
+        dy = dy.contiguous().to(y.dtype)
+        chunks = _abi.lib.ppea_bias_elu_chunks(N, C, HW)
+        partial = torch.empty(N, C, chunks, device=y.device, dtype=_F32)
+        dz = torch.empty_like(y)
+        call(f"ppea_bias_elu_bwd_{_suffix(y)}", ptr(dy), ptr(y), ptr(dz), ptr(partial), N, C, HW, stream_ptr())
+        return dz, partial.sum((0, 2)).to(ctx.bdt)
+
+
+def bias_elu(z, bias):
+    """elu(z + bias[None, :, None, None]) in one pass; the bias gradient comes out of the backward pass."""
+    return _BiasElu.apply(z, bias)
+
+
+# ---------------------------------------------------------------------------------------------
 # A12 glue: ReflectionPad2d(1)                                            layers.py:119-135
 # ---------------------------------------------------------------------------------------------
 class _ReflectPad1(torch.autograd.Function):

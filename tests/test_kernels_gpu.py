@@ -457,3 +457,25 @@ def test_adam_flat_matches_torch_adam(device):
              stream_ptr())
         assert (P - ref.detach()).abs().max() <= 2e-7 * ref.detach().abs().max() + 1e-9, step
     assert torch.equal(W16, P[:n_lo].bfloat16())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 5, 7, 9), (3, 16, 24, 80), (1, 4, 192, 640)])
+def test_bias_elu(device, dtype, shape):
+    """elu(z + b) in one pass; backward = dz and the bias gradient (per-plane partial sums)."""
+    import torch.nn.functional as F
+    from ppeadepth import ops
+    g = _g(shape[1])
+    z = torch.randn(shape, generator=g).to(dtype)
+    b = torch.randn(shape[1], generator=g)
+    go = torch.randn(shape, generator=g).to(dtype)
+    zr, br = z.float().clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.elu(zr + br.view(1, -1, 1, 1))
+    (ref * go.float()).sum().backward()
+    zd, bd = z.to(device).requires_grad_(True), b.to(device).requires_grad_(True)
+    y = ops.bias_elu(zd, bd)
+    (y.float() * go.to(device).float()).sum().backward()
+    tol = 2e-6 if dtype == torch.float32 else 1e-2
+    assert rel_err(y.float().cpu(), ref.detach()) < tol
+    assert rel_err(zd.grad.float().cpu(), zr.grad) < max(tol, 1e-5)
+    assert rel_err(bd.grad.cpu(), br.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
