@@ -159,6 +159,9 @@ int ppea_bn_bwd_reduce_final_bf16(const void* dy, const void* z1, const void* z2
  * local statistics in wire layout packed[2C+1] = mean[C] | biased var[C] | count, and the Chan combine of the
  * gathered [world][2C+1] table into mean / invstd (running statistics updated unless running_mean is NULL). */
 int ppea_bn_finalize_packed_f32(const float* partial, int N, int C, int HW, float* packed, void* stream);
+/* same wire layout straight from the tensor in one launch (small channels; PPEA_ERR_UNSUPPORTED otherwise) */
+int ppea_bn_stats_packed_f32(const void* z, int N, int C, int HW, float* packed, void* stream);
+int ppea_bn_stats_packed_bf16(const void* z, int N, int C, int HW, float* packed, void* stream);
 int ppea_bn_sync_combine_f32(const float* gathered, int world, int C, float eps, float momentum, float* mean,
                              float* invstd, float* running_mean, float* running_var, void* stream);
 int ppea_bn_apply_f32(const void* z1, const void* z2, const float* const* stats, const float* mask,

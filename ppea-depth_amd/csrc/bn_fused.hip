@@ -417,10 +417,12 @@ __global__ __launch_bounds__(TPB) void bn_stats_channel(const T* __restrict__ z,
                                                         float momentum, float* __restrict__ mean_out,
                                                         float* __restrict__ var_out, float* __restrict__ invstd_out,
                                                         float* __restrict__ running_mean,
-                                                        float* __restrict__ running_var) {
+                                                        float* __restrict__ running_var,
+                                                        float* __restrict__ count_out) {
     __shared__ float red[4];
     const int c = blockIdx.x;
     const int hv = HW / V, total = N * hv;              // vectors per plane / per channel
+    if (count_out != nullptr && c == 0 && threadIdx.x == 0) *count_out = (float)N * (float)HW;
     // every load of the channel is issued before the first use: one memory latency for the whole pass, and
     // the values stay in registers for the second (centred) pass
     float x[CH_VECS][V];
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(TPB) void bn_stats_channel(const T* __restrict__ z,
         const float var = m2 / cnt;
         mean_out[c] = mean;
         var_out[c] = var;
-        invstd_out[c] = rsqrtf(var + eps);
+        if (invstd_out != nullptr) invstd_out[c] = rsqrtf(var + eps);
         if (running_mean != nullptr) {
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / fmaxf(cnt - 1.f, 1.f));
@@ -655,7 +657,17 @@ int stats_final_impl(const void* z, int N, int C, int HW, float eps, float momen
                      float* invstd, float* running_mean, float* running_var, void* stream) {
     if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS) return PPEA_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(bn_stats_channel<T>, dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream,
-                       (const T*)z, N, C, HW, eps, momentum, mean, var, invstd, running_mean, running_var);
+                       (const T*)z, N, C, HW, eps, momentum, mean, var, invstd, running_mean, running_var,
+                       (float*)nullptr);
+    return launch_status();
+}
+// SyncBN wire format packed[2C+1] = mean | biased var | count in one launch (small channels)
+template <typename T>
+int stats_packed_impl(const void* z, int N, int C, int HW, float* packed, void* stream) {
+    if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS) return PPEA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bn_stats_channel<T>, dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream,
+                       (const T*)z, N, C, HW, 0.f, 0.f, packed, packed + C, (float*)nullptr, (float*)nullptr,
+                       (float*)nullptr, packed + 2 * C);
     return launch_status();
 }
 template <typename T>
@@ -699,6 +711,12 @@ int ppea_bn_bwd_reduce_final_f32(const void* dy, const void* z1, const void* z2,
 int ppea_bn_bwd_reduce_final_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
                                   const float* mask, float* sums, int act, int N, int C, int HW, void* stream) {
     return bwd_reduce_final_impl<uint16_t>(dy, z1, z2, stats, mask, sums, act, N, C, HW, stream);
+}
+int ppea_bn_stats_packed_f32(const void* z, int N, int C, int HW, float* packed, void* stream) {
+    return stats_packed_impl<float>(z, N, C, HW, packed, stream);
+}
+int ppea_bn_stats_packed_bf16(const void* z, int N, int C, int HW, float* packed, void* stream) {
+    return stats_packed_impl<uint16_t>(z, N, C, HW, packed, stream);
 }
 int ppea_bn_finalize_packed_f32(const float* partial, int N, int C, int HW, float* packed, void* stream) {
     if (N <= 0 || C <= 0 || HW <= 0) return PPEA_ERR_UNSUPPORTED;

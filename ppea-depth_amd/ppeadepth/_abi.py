@@ -52,6 +52,8 @@ SIGNATURES = {
     "ppea_bn_stats_final_bf16": [_vp, _i, _i, _i, _f, _f] + [_vp] * 5 + [_vp],
     "ppea_bn_bwd_reduce_final_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_bn_bwd_reduce_final_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_bn_stats_packed_f32": [_vp, _i, _i, _i, _vp, _vp],
+    "ppea_bn_stats_packed_bf16": [_vp, _i, _i, _i, _vp, _vp],
     "ppea_bn_finalize_packed_f32": [_vp, _i, _i, _i, _vp, _vp],
     "ppea_bn_sync_combine_f32": [_vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "ppea_bn_apply_f32": [_vp] * 6 + [_f, _vp] + [_i] * 4 + [_vp],

@@ -391,8 +391,13 @@ def bn_local_stats_packed(z):
     z = z.contiguous()
     N, C = z.shape[0], z.shape[1]
     HW = z.numel() // (N * C)
-    partial = torch.empty(C * N * 2, device=z.device, dtype=_F32)
     packed = torch.empty(2 * C + 1, device=z.device, dtype=_F32)
+    err = getattr(_abi.lib, f"ppea_bn_stats_packed_{_suffix(z)}")(ptr(z), N, C, HW, ptr(packed), stream_ptr())
+    if err == 0:
+        return packed
+    if err != -1:
+        _abi.check(err, "ppea_bn_stats_packed")
+    partial = torch.empty(C * N * 2, device=z.device, dtype=_F32)
     call(f"ppea_bn_stats_{_suffix(z)}", ptr(z), ptr(partial), N, C, HW, stream_ptr())
     call("ppea_bn_finalize_packed_f32", ptr(partial), N, C, HW, ptr(packed), stream_ptr())
     return packed
