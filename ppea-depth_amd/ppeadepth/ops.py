@@ -18,9 +18,13 @@ _BF16 = torch.bfloat16
 PROFILE_DWCONV = None
 
 
+PROFILE_REPLAY = {}       # kind -> closure re-issuing the first profiled launch of that kind (same arguments)
+
+
 def _timed(kind, K, fn):
     if PROFILE_DWCONV is None or K != 31:
         return fn()
+    PROFILE_REPLAY.setdefault(kind, fn)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     r = fn()
