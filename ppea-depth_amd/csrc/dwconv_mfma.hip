@@ -24,6 +24,16 @@
 #include "common.h"
 #include <utility>
 
+#ifdef DW_PROF
+// Phase timing (tools/dwconv_phases.py builds a separate library with -DDW_PROF): s_memtime deltas per wave.
+__device__ unsigned long long g_dw_prof[4096][8];
+#define PROF_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define PROF_ADD(slot, a, b) prof[slot] += (b) - (a)
+#else
+#define PROF_T(v)
+#define PROF_ADD(slot, a, b)
+#endif
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -64,7 +74,7 @@ constexpr int NCOPY = 4;
 constexpr int packed_elems(int K) { return NCOPY * K * WPAD; }
 
 template <int K, int P, int JOFF>
-__device__ __forceinline__ bf16x8 load_bfrag(const uint16_t* img, int ky, int s, int lane) {
+__device__ __forceinline__ bf16x8 load_bfrag(const uint16_t* __restrict__ img, int ky, int s, int lane) {
     const int i0 = 32 + 32 * s + 8 * (lane >> 4) - (lane & 15) + (P - JOFF);
     const int copy = i0 & 3;
     const uint2* p = reinterpret_cast<const uint2*>(img + (copy * K + ky) * WPAD + (i0 - copy));
@@ -309,11 +319,11 @@ __device__ __forceinline__ void stream_step(f32x4 (&accb)[2], f32x4& accs, bf16x
     if constexpr (I < TOTAL) {
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[I % RING]) : "i"(DIST - 1));
         if constexpr (I < K * NS)
-            accb[I & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[I % RING], bfb[I / NS][I % NS], accb[I & 1], 0, 0, 0);
+            accb[I & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfb[I / NS][I % NS], cur[I % RING], accb[I & 1], 0, 0, 0);
         else if constexpr (MODE == 0)
-            accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[I % RING], bfs[I - K * NS][0], accs, 0, 0, 0);
+            accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfs[I - K * NS][0], cur[I % RING], accs, 0, 0, 0);
         else
-            accb[I & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[I % RING], bfs[I - K * NS][0], accb[I & 1], 0, 0, 0);
+            accb[I & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfs[I - K * NS][0], cur[I % RING], accb[I & 1], 0, 0, 0);
         constexpr int J = I + DIST;
         if constexpr (J < TOTAL) stream_read<K, KS, NS, STRIDE_B, SM_ROW0, J>(cur[J % RING], tc);
         else stream_read<K, KS, NS, STRIDE_B, SM_ROW0, J - TOTAL>(nxt[(J - TOTAL) % RING], tn);
@@ -321,31 +331,39 @@ __device__ __forceinline__ void stream_step(f32x4 (&accb)[2], f32x4& accs, bf16x
     }
 }
 
-// Per M-tile: element offsets of this lane's four output rows (-1 = padding row).
-struct RowOffs { int off[4]; };
+// The MFMAs take the Toeplitz fragment as the A operand and the input rows as B (both fragment layouts are
+// "index = lane & 15, k = 8 * (lane >> 4) + j", so the registers are the same either way): the accumulator then
+// holds the TRANSPOSED tile -- lane (y = lane & 15, g = lane >> 4) owns columns 4g..4g+3 of image row y, four
+// consecutive bf16 = ONE 8-byte store per lane instead of four 2-byte ones.
+// Per M-tile: element offset of this lane's output row (-1 = padding row).
+struct RowOffs { int off; };
 
 __device__ __forceinline__ RowOffs row_offsets(const Item& it, int C, int c, int H, int W, int mt, int lane) {
     RowOffs ro;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = mt * 16 + 4 * (lane >> 4) + i;           // stacked output row
-        const int g = m / it.rows, y = it.y0 + (m - g * it.rows);
-        ro.off[i] = (g < it.G && y < H) ? (((it.n0 + g) * C + c) * H + y) * W : -1;
-    }
+    const int m = mt * 16 + (lane & 15);                       // stacked output row
+    const int g = m / it.rows, y = it.y0 + (m - g * it.rows);
+    ro.off = (g < it.G && y < H) ? (((it.n0 + g) * C + c) * H + y) * W : -1;
     return ro;
 }
 
-__device__ __forceinline__ uint16_t to_bf16_hw(float f) {      // v_cvt_pk_bf16_f32 (RNE, NaN kept)
-    return __builtin_bit_cast(uint16_t, (__bf16)f);
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {      // v_cvt_pk_bf16_f32 (RNE, NaN kept)
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 __device__ __forceinline__ void store_tile(uint16_t* __restrict__ dst, const f32x4& acc, const RowOffs& ro, int W,
                                            int xt, int lane) {
-    const int col = xt + (lane & 15);
-    if (col >= W) return;
+    const int col = xt + 4 * (lane >> 4);
+    if (ro.off < 0 || col >= W) return;
+    uint16_t* p = dst + ro.off + col;
+    if (col + 4 <= W && ((ro.off + col) & 3) == 0) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]));
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (ro.off[i] >= 0) dst[ro.off[i] + col] = to_bf16_hw(acc[i]);
+        for (int i = 0; i < 4; ++i)
+            if (col + i < W) p[i] = __builtin_bit_cast(uint16_t, (__bf16)acc[i]);
+    }
 }
 
 // MODE 0: fwd  (in0 = x; out0 = y_big, out1 = y_small if KS)
@@ -371,12 +389,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     if (wid >= total_waves) return;
     const int c = (int)(wid / wpc);
     const int first_item = (int)(wid - (long)c * wpc) * ipw;
-    uint8_t* region = smem + (long)wave * region_bytes;
-    copy_image(region, w_big + (long)c * packed_elems(K), packed_elems(K), lane);
-    if constexpr (KS > 0)
-        copy_image(region + packed_elems(K) * 2, w_small + (long)c * packed_elems(KS), packed_elems(KS), lane);
-    const uint16_t* wimg_b = reinterpret_cast<const uint16_t*>(region);
-    const uint16_t* wimg_s = wimg_b + packed_elems(K);
+#ifdef DW_PROF
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    PROF_T(t_begin);
+    // The Toeplitz fragments come straight from the packed image in global memory (L2: the waves of a channel
+    // read the same 24 KB): 2 x 8 bytes per fragment and lane, all issued before the first wait.  (Staging the
+    // image through LDS first cost 17-32 % of a wave's time.)
+    const uint16_t* wimg_b = w_big + (long)c * packed_elems(K);
+    const uint16_t* wimg_s = (KS > 0) ? w_small + (long)c * packed_elems(KS) : nullptr;
 
     // Toeplitz fragments of the whole filter: registers for the rest of the kernel
     bf16x8 bf_big[K][GE::NS];
@@ -396,8 +417,6 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) bf_small[ky][0] = load_bfrag<KS, GS::P, GS::JOFF>(wimg_s, ky, 0, lane);
     }
-    // the fragment reads above must have completed before the tile staging overwrites the image
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     uint8_t* tile0 = smem + (long)wave * region_bytes;
     uint8_t* tile1 = tile0 + tile_bytes;
@@ -434,7 +453,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
         stage_load<K, NSEG>(pre, in0, it, C, c, H, W, lane);
     }
 
+    PROF_T(t_setup_done);
+    PROF_ADD(0, t_begin, t_setup_done);
     while (have) {
+        PROF_T(t_item);
         // The tile is wave-private: LDS operations of one wave execute in order, so the staging writes
         // below are ordered after the previous item's (already waited-for) reads and before this item's.
         Item nxt;
@@ -452,6 +474,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
             if constexpr (NT_IN == 2) stage_planes<K, NSEG>(tile1, in1, it, C, c, H, W, lane);
         }
         asm volatile("" ::: "memory");      // compiler fence: staging stores stay above the asm LDS reads
+        PROF_T(t_staged);
+        PROF_ADD(1, t_item, t_staged);
 
         const int rows_l = it.rows + K - 1;                 // LDS rows per stacked image (with halo)
         const int ntiles_x = min(NSEG, (W - it.x0 + 15) / 16);
@@ -481,22 +505,35 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
             const TileBase tn = last ? tc : tile_base(mt2, nt2);        // last tile: harmless re-reads, drained below
             f32x4 accb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             f32x4 accs = {0.f, 0.f, 0.f, 0.f};
+            PROF_T(t_mac0);
             stream_step<K, KS, MODE, GE::NS, STRIDE_B, SM_ROW0, 0>(accb, accs, cur, nxt_ring, tc, tn, bf_big, bf_small);
+            PROF_T(t_mac1);
+            PROF_ADD(2, t_mac0, t_mac1);
             const f32x4 acc = accb[0] + accb[1];
             store_tile(out0, acc, ro, W, it.x0 + nt * 16, lane);
             if constexpr (MODE == 0 && KS > 0) store_tile(out1, accs, ro, W, it.x0 + nt * 16, lane);
             if (mt2 != mt && !last) ro = row_offsets(it, C, c, H, W, mt2, lane);
             mt = mt2; nt = nt2; tc = tn;
+            PROF_T(t_epi);
+            PROF_ADD(3, t_mac1, t_epi);
         };
         for (int t = 0; t < ntiles; t += 2) {
             one_tile(ringA, ringB, t);
             if (t + 1 < ntiles) one_tile(ringB, ringA, t + 1);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the look-ahead reads of the last tile
+        PROF_T(t_item_end);
+        PROF_ADD(4, t_item, t_item_end);
         asm volatile("" ::: "memory");      // next item's staging stores stay below this item's LDS reads
         it = nxt;
         have = have_next;
     }
+#ifdef DW_PROF
+    PROF_T(t_end);
+    prof[5] = t_end - t_begin;
+    if (lane == 0 && wid < 4096)
+        for (int i = 0; i < 8; ++i) g_dw_prof[wid][i] = prof[i];
+#endif
 }
 
 template <int K, int KS, int MODE, int NSEG>
@@ -579,6 +616,12 @@ int dispatch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const
 }  // namespace
 
 extern "C" {
+
+#ifdef DW_PROF
+int ppea_debug_dwconv_prof(unsigned long long* out) {   // host buffer [4096][8]
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_prof), sizeof(unsigned long long) * 4096 * 8);
+}
+#endif
 
 long ppea_dwconv_lk_packed_bytes(int C, int K) {
     if (C <= 0 || K < 3 || K > 31 || (K & 1) == 0) return -1;
