@@ -217,8 +217,8 @@ def main():
                     # HBM-side bytes per launch from the PMC passes committed in profiles/r01_pmc_dwconv_pwconv.csv
                     # (separate --pmc runs; FETCH_SIZE in KB doubled for 16-byte-per-lane loads on gfx950 as
                     # MI355X_MICROARCH.md prescribes, WRITE_SIZE in KB as reported)
-                    roof["traffic"] = int((2 * 20353.2 + 51162.4) * 1024)
-                    roof["traffic_note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline; 1.29x the algorithmic bytes (column halo re-reads)"
+                    roof["traffic"] = int((2 * 20401.8 + 51014.6) * 1024)
+                    roof["traffic_note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline; 1.32x the algorithmic bytes (column halo re-reads)"
             else:
                 roof.update({"name": "dwconv_lk_kernel<float,31,5,...>",
                              "binding_roof": "fp32 vector FMA (AI ~ %d F/B)" % round(useful / bytes_alg),
