@@ -19,6 +19,7 @@ import json
 import os
 import random
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -147,42 +148,7 @@ def main():
     # Several ranks: the captured step also holds the RCCL calls (SyncBN all-gathers / all-reduces on per-branch
     # communicators, the gradient all-reduce on a side stream).  Capture is attempted on every rank; if any
     # rank fails, all fall back to eager launches (PPEA_MULTI_GRAPH=0 skips the attempt).
-    multi = pdist.collectives_on()
-    use_graph = (not args.eager) and (not multi or os.environ.get("PPEA_MULTI_GRAPH", "1") == "1")
-    if use_graph:
-        ok = 1
-        try:
-            engine.capture(inputs, warmup=1)
-        except Exception as ex:                  # noqa: BLE001 -- any capture failure means eager
-            ok = 0
-            print(f"[bench] rank {rank}: graph capture failed ({type(ex).__name__}: {ex}); eager fallback",
-                  file=sys.stderr, flush=True)
-        if multi:
-            flag = torch.tensor([ok], device=device, dtype=torch.int32)
-            torch.cuda.synchronize()
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag)
-        if not ok:
-            engine.graph = None
-            use_graph = False
-    args.eager = not use_graph
-    if use_graph:
-        for _ in range(2):
-            engine.step(inputs)
-    barrier()
-    t0 = time.time()
-    for _ in range(args.steps):
-        _, losses = engine.step(dict(inputs) if args.eager else inputs)
-    barrier()
-    dt = time.time() - t0
-    loss_val = float(losses["loss"])
-
-    t = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t)
-
-    if rank == 0:
+    def make_line(dt, loss_val, launch):
         # ---- roofline of the 31x31 depthwise conv (fwd launches with the fused 5x5 branch) ------
         es = 2 if args.dtype == "bf16" else 4
         C0 = 128 if args.rep_size == "b" else 192
@@ -235,16 +201,85 @@ def main():
                                    "process_batch + backward + grad all-reduce + Adam",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "use_checkpoint": "BN-stat replay, no recompute (288 GB HBM)",
-                       "launch": "eager" if args.eager else "whole step captured in one hipGraph"},
+                       "launch": launch},
             "final_loss": round(loss_val, 5),
             "roofline": roof,
         }
+
+        return line
+
+    multi = pdist.collectives_on()
+    use_graph = (not args.eager) and (not multi or os.environ.get("PPEA_MULTI_GRAPH", "1") == "1")
+
+    def timed(eager):
+        """EXACTLY args.steps steps between barriers; max over ranks."""
+        barrier()
+        t0 = time.time()
+        for _ in range(args.steps):
+            _, ls = engine.step(dict(inputs) if eager else inputs)
+        barrier()
+        el = torch.tensor([time.time() - t0], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el), float(ls["loss"].detach())
+
+    # Several ranks: the captured step holds RCCL calls on two communicators next to the compute branches.  That
+    # combination cannot run on the one-GPU development box, so it is fenced twice: the eager measurement is taken
+    # FIRST, and a watchdog prints that line and ends the process if capture + replay has not finished in time.
+    fallback, watchdog = None, None
+    if multi and use_graph:
+        fallback = timed(eager=True)
+        deadline = float(os.environ.get("PPEA_GRAPH_DEADLINE_S", "240"))
+
+        def on_timeout():
+            print(f"[bench] rank {rank}: captured step did not finish within {deadline:.0f} s; reporting the eager run",
+                  file=sys.stderr, flush=True)
+            if rank == 0:
+                emit(fallback[0], fallback[1], True, "eager (captured multi-rank step timed out)")
+            os._exit(0)
+        watchdog = threading.Timer(deadline, on_timeout)
+        watchdog.daemon = True
+
+    def emit(dt, loss_val, eager, launch):
+        line = make_line(dt, loss_val, launch)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()
             except Exception as ex:          # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)
+
+    if watchdog is not None:
+        watchdog.start()
+    if use_graph:
+        ok = 1
+        try:
+            engine.capture(inputs, warmup=1)
+        except Exception as ex:                  # noqa: BLE001 -- any capture failure means eager
+            ok = 0
+            print(f"[bench] rank {rank}: graph capture failed ({type(ex).__name__}: {ex}); eager fallback",
+                  file=sys.stderr, flush=True)
+        if multi:
+            flag = torch.tensor([ok], device=device, dtype=torch.int32)
+            torch.cuda.synchronize()
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag)
+        if not ok:
+            engine.graph = None
+            use_graph = False
+    args.eager = not use_graph
+    if use_graph:
+        for _ in range(2):
+            engine.step(inputs)
+    if use_graph or fallback is None:
+        dt, loss_val = timed(eager=args.eager)
+    else:
+        dt, loss_val = fallback
+    if watchdog is not None:
+        watchdog.cancel()
+
+    if rank == 0:
+        emit(dt, loss_val, args.eager, "eager" if args.eager else "whole step captured in one hipGraph")
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
