@@ -40,7 +40,7 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak
 def cpu_baseline(seconds_budget=40.0):
     """The oracle's full training step on the host CPU: B=2, 192x640, fp32 (config 1)."""
     import types
-    from oracle import model_spec, ref_model, synth
+    from oracle import model_spec, ref_model, synth          # the CPU baseline IS the oracle
     B, H, W = 2, 192, 640
     opt = types.SimpleNamespace(rep_size="b", g_blk=1.0, g_ffn=1.0, use_checkpoint=False, height=H, width=W,
                                 batch_size=B, num_depth_bins=96, min_depth=0.1, max_depth=100.0,
@@ -84,7 +84,7 @@ def main():
     from ppeadepth import dist as pdist
     from ppeadepth import networks, options, ops, rng
     from ppeadepth.trainer import Trainer
-    from oracle import synth
+    from ppeadepth import synthetic as synth
 
     rank, local_rank, world = pdist.init_distributed()
     if os.environ.get("PPEA_STREAMS") is not None:       # parallel graph branches on/off (default on)

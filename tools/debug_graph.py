@@ -41,7 +41,7 @@ elif which in ("fwd", "fwdbwd", "step"):
     from ppeadepth import networks, options, rng
     from ppeadepth.trainer import Trainer
     from ppeadepth.dist import TrainEngine
-    from oracle import synth
+    from ppeadepth import synthetic as synth
     B, H, W = 2, 64, 96
     opt = options.default_options(height=H, width=W, batch_size=B)
     model = networks.RepDepth(opt); synth.fill_state_dict(model); model.to(dev).train()

@@ -57,7 +57,7 @@ def run():
     from ppeadepth import dist as pdist
     from ppeadepth import networks, options, rng
     from ppeadepth.trainer import Trainer
-    from oracle import synth
+    from ppeadepth import synthetic as synth
 
     dev = torch.device("cuda", 0)
     H, W, B = 192, 640, int(os.environ.get("SEG_BATCH", "12"))
