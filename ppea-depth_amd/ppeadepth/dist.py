@@ -293,6 +293,10 @@ class TrainEngine:
         for p in self.params:
             p.grad = None              # autograd then hands each gradient over without an accumulate kernel
         losses["loss"].backward()
+        self._optimizer_phase()
+        return outputs, losses
+
+    def _optimizer_phase(self):
         if self.flat is not None:      # pack -> (several ranks: few large all-reduces) -> Adam on the flat buffer
             self.flat.gather(self.params)
             self.flat.all_reduce_mean()
@@ -307,7 +311,6 @@ class TrainEngine:
             if self._lo:
                 with torch.no_grad():
                     torch._foreach_copy_(self._lo, self._hi)  # masters -> bf16 working weights
-        return outputs, losses
 
     def step(self, inputs):
         if self.graph is not None:

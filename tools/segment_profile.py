@@ -69,6 +69,8 @@ def run():
     trainer = Trainer(opt, model, dev, amp_dtype=torch.bfloat16)
     engine = pdist.TrainEngine(trainer, bf16_params=True)
     rng.set_mode("device")
+    networks.repdepth.TWO_STREAMS = False            # one stream: markers and kernels in one time order
+    networks.replknet_adapter.ADAPTER_STREAMS = False
     inputs = {k: v.to(dev) for k, v in synth.make_inputs(B, H, W, seed=1234, smooth=True).items()}
     random.seed(1000)
     for _ in range(3):
@@ -132,14 +134,7 @@ def run():
             losses["loss"].backward()
             marker(phases["backward"][1])
             marker(phases["optimizer"][0])
-            with torch.no_grad():
-                if engine._lo:
-                    torch._foreach_copy_(engine._hi_grads, [p.grad if p.grad is not None else torch.zeros_like(p)
-                                                            for p in engine._lo])
-            engine.optimizer.step()
-            with torch.no_grad():
-                if engine._lo:
-                    torch._foreach_copy_(engine._lo, engine._hi)
+            engine._optimizer_phase()
             marker(phases["optimizer"][1])
         marker(N_CAL + 1)                 # end sentinel
         torch.cuda.synchronize()
