@@ -103,6 +103,8 @@ def main():
     model = networks.RepDepth(opt)
     synth.fill_state_dict(model)                 # deterministic random-init weights (no checkpoints offline)
     model.to(device).train()
+    if os.environ.get("PPEA_EXPERIMENT_FREEZE_POSE") == "1":   # what-if probe (which branch is critical), not a benchmark mode
+        model.freeze_pose_net()
     pdist.broadcast_module(model)
     if pdist.collectives_on():
         from ppeadepth import batchnorm
