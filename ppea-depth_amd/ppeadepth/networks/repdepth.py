@@ -24,6 +24,8 @@ _ENC_CH = {"b": [128, 256, 512, 1024], "l": [192, 384, 768, 1536]}
 
 
 TWO_STREAMS = True
+BATCHED_POSES = True      # third (no_grad) pose pass replayed instead of recomputed (see _predict_poses_batched)
+POSE_ONE_BATCH = False
 
 
 def _g(opt, name, default):
@@ -139,6 +141,51 @@ class RepDepth(nn.Module):
         return st
 
     def predict_poses(self, inputs):
+        if (BATCHED_POSES and self.training and list(self.opt.frame_ids) == [0, -1, 1]
+                and list(self.matching_ids) == [0, -1]):
+            return self._predict_poses_batched(inputs)
+        return self._predict_poses_sequential(inputs)
+
+    def _predict_poses_batched(self, inputs):
+        """The reference runs the pose network three times per step: pairs (-1, 0) and (0, +1) with gradients, then
+        (-1, 0) AGAIN without, for the matching frame (repdepth.py:443-509).  The third pass has the same input and
+        the same weights as the first, so its outputs are the first pass's and the only thing it changes is one more
+        BatchNorm running-statistics update with the first pass's batch statistics: that update is replayed
+        (GroupBN.replay_update) and the pass itself is skipped.  POSE_ONE_BATCH additionally sends both pairs through
+        the network as one 2B batch with per-sub-batch statistics (measured slower: the per-layer concatenations
+        cost more than the halved launch count saves)."""
+        outputs = {}
+        f = {i: inputs[("color_aug", i, 0)] for i in (0, -1, 1)}
+        B = f[0].shape[0]
+        pairs = {-1: torch.cat([f[-1], f[0]], 1), 1: torch.cat([f[0], f[1]], 1)}
+        if POSE_ONE_BATCH:
+            aa2, tt2 = self.pose([self.pose_encoder(torch.cat([pairs[-1], pairs[1]], 0), groups=2, record=True)])
+            res = {-1: (aa2[:B], tt2[:B]), 1: (aa2[B:], tt2[B:])}
+            recorded = self.pose_encoder.recorded
+        else:
+            snap = self.pose_encoder.snapshot_running()
+            res = {-1: self.pose([self.pose_encoder(pairs[-1])])}
+            stats_a = self.pose_encoder.batch_stats_since(snap)
+            res[1] = self.pose([self.pose_encoder(pairs[1])])
+            recorded = None
+        for f_i in (-1, 1):
+            aa, tt = res[f_i]
+            outputs[("axisangle", 0, f_i)] = aa
+            outputs[("translation", 0, f_i)] = tt
+            outputs[("cam_T_cam", 0, f_i)] = transformation_from_parameters(aa[:, 0], tt[:, 0], invert=(f_i < 0))
+        with torch.no_grad():
+            if recorded is not None:                                          # the no_grad pass on pair (-1, 0)
+                for bn, mean, invstd, count in recorded:
+                    bn.replay_update(mean, invstd, count)
+                self.pose_encoder.recorded = None
+            else:
+                self.pose_encoder.replay_pass(stats_a)
+            pose = outputs[("cam_T_cam", 0, -1)].detach()
+            present = (f[-1].flatten(1).sum(1) != 0).to(pose.dtype)
+            inputs[("relative_pose", -1)] = pose * present[:, None, None]
+        return outputs
+
+    def _predict_poses_sequential(self, inputs):
         outputs = {}
         frames = {f: inputs[("color_aug", f, 0)] for f in self.opt.frame_ids}
         for f_i in self.opt.frame_ids[1:]:

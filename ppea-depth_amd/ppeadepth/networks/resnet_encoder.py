@@ -11,16 +11,49 @@ import torch.nn as nn
 CHANNELS_LAST = True
 
 
+class GroupBN(nn.BatchNorm2d):
+    """nn.BatchNorm2d (same parameters / buffers / state_dict keys) that can treat its batch as `groups`
+    consecutive sub-batches, each normalised with ITS OWN batch statistics and each updating the running
+    statistics in turn -- exactly what separate forward calls on the sub-batches do.  This lets the pose network
+    see both frame pairs of a step as one batch of 2B (convolutions launched once, not twice) without changing
+    a number.  With `record` set the sub-batch statistics are kept so that a further call on the same data (the
+    reference's no_grad pose pass for the matching frames) can be replayed as a running-statistics update."""
+    groups = 1
+    record = None           # None, or a list that receives (mean, invstd, count) per sub-batch
+
+    def forward(self, x):
+        if not self.training or (self.groups == 1 and self.record is None):
+            return super().forward(x)
+        outs = []
+        for chunk in x.chunk(self.groups, 0):
+            y, mean, invstd = torch.native_batch_norm(chunk, self.weight, self.bias, self.running_mean,
+                                                      self.running_var, True, self.momentum, self.eps)
+            self.num_batches_tracked += 1
+            if self.record is not None:
+                self.record.append((mean.detach(), invstd.detach(), chunk.numel() // chunk.shape[1]))
+            outs.append(y)
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
+
+    def replay_update(self, mean, invstd, count):
+        """Running-statistics update of one more training-mode forward on a batch with these statistics."""
+        var = (1.0 / (invstd * invstd) - self.eps) * (count / max(count - 1, 1))
+        # through .data: like the update inside the batch-norm kernel, this must not bump the version counter of the
+        # buffers autograd holds for the backward of the passes above
+        self.running_mean.data.lerp_(mean.to(self.running_mean.dtype), self.momentum)
+        self.running_var.data.lerp_(var.to(self.running_var.dtype), self.momentum)
+        self.num_batches_tracked += 1
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = GroupBN(planes)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = GroupBN(planes)
         self.downsample = downsample
         self.stride = stride
 
@@ -38,7 +71,7 @@ class ResNetMultiImageInput(nn.Module):
         super().__init__()
         self.inplanes = 64
         self.conv1 = nn.Conv2d(num_input_images * 3, 64, 7, 2, 3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = GroupBN(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
         self.layer1 = self._make_layer(64, layers[0])
@@ -57,7 +90,7 @@ class ResNetMultiImageInput(nn.Module):
     def _make_layer(self, planes, blocks, stride=1):
         down = None
         if stride != 1 or self.inplanes != planes:
-            down = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), GroupBN(planes))
         layers = [BasicBlock(self.inplanes, planes, stride, down)]
         self.inplanes = planes
         layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
@@ -78,7 +111,53 @@ class ResnetEncoder(nn.Module):
             if "fc" in name:
                 p.requires_grad = False
 
-    def forward(self, input_image):
+    def forward(self, input_image, groups=1, record=False):
+        """groups > 1: the batch is `groups` consecutive sub-batches with separate BatchNorm statistics (see GroupBN);
+        record: keep the first sub-batch's statistics in `self.recorded` [(bn, mean, invstd, count)]."""
+        e = self.encoder
+        bns = [m for m in e.modules() if isinstance(m, GroupBN)]
+        for m in bns:
+            m.groups = groups
+            m.record = [] if record else None
+        try:
+            feats = self._forward(input_image)
+        finally:
+            if record:
+                self.recorded = [(m,) + m.record[0] for m in bns if m.record]
+            for m in bns:
+                m.groups, m.record = 1, None
+        return feats
+
+    # -- running-statistics bookkeeping for a forward pass that is replayed instead of recomputed -----------------
+    def running_buffers(self):
+        bns = [m for m in self.encoder.modules() if isinstance(m, nn.BatchNorm2d)]
+        return bns, [m.running_mean for m in bns] + [m.running_var for m in bns]
+
+    def snapshot_running(self):
+        """Copies of all running means / variances (multi-tensor copy), taken BEFORE a training-mode pass."""
+        _, bufs = self.running_buffers()
+        with torch.no_grad():
+            return [b.clone() for b in bufs]
+
+    def batch_stats_since(self, snap):
+        """Batch statistics (mean | unbiased var per layer) of the ONE training-mode pass run since `snap`, recovered
+        from the momentum update r1 = (1 - m) r0 + m s  ->  s = (r1 - (1 - m) r0) / m."""
+        bns, bufs = self.running_buffers()
+        m = bns[0].momentum
+        with torch.no_grad():
+            scaled = torch._foreach_mul(snap, 1.0 - m)
+            diff = torch._foreach_sub([b.detach() for b in bufs], scaled)
+            return torch._foreach_div(diff, m)
+
+    def replay_pass(self, stats):
+        """Running-statistics effect of one more training-mode pass over a batch with these statistics."""
+        bns, bufs = self.running_buffers()
+        with torch.no_grad():
+            torch._foreach_lerp_([b.data for b in bufs], stats, bns[0].momentum)   # .data: no version bump
+            for bn in bns:
+                bn.num_batches_tracked += 1
+
+    def _forward(self, input_image):
         e = self.encoder
         x = (input_image - 0.45) / 0.225
         if CHANNELS_LAST and x.is_cuda:

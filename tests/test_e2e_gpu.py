@@ -157,3 +157,32 @@ def test_bf16_params_with_fp32_masters_and_graph_replay(device):
     sd = eng.export_state_dict()
     assert len(sd) == n_keys and all(v.dtype != torch.bfloat16 for v in sd.values())
     rng.set_aug_buffer(None)
+
+
+@pytest.mark.parametrize("one_batch", [False, True])
+def test_pose_pass_replay_equals_three_sequential_passes(device, one_batch):
+    """repdepth.py:443-509 runs the pose network three times per step (the third, no_grad, on the first pair again).
+    The product replays the third pass as a running-statistics update (and can batch the first two): poses, the
+    matching frame's relative pose and EVERY BatchNorm buffer of the pose network must come out the same."""
+    import copy
+    from ppeadepth.networks import repdepth
+    opt, model, tr = _build(device, 2, 64, 96, False)
+    inputs = {k: v.to(device) for k, v in synth.make_inputs(2, 64, 96).items()}
+    ref_model = copy.deepcopy(model)
+    a_in, b_in = dict(inputs), dict(inputs)
+    out_ref = ref_model._predict_poses_sequential(a_in)
+    old = repdepth.POSE_ONE_BATCH
+    repdepth.POSE_ONE_BATCH = one_batch
+    try:
+        out_new = model._predict_poses_batched(b_in)
+    finally:
+        repdepth.POSE_ONE_BATCH = old
+    for k, v in out_ref.items():
+        assert rel_err(out_new[k].detach().cpu(), v.detach().cpu()) < 1e-5, k
+    assert rel_err(b_in[("relative_pose", -1)].cpu(), a_in[("relative_pose", -1)].cpu()) < 1e-5
+    sd_ref, sd_new = ref_model.pose_encoder.state_dict(), model.pose_encoder.state_dict()
+    for k, v in sd_ref.items():
+        if "running" in k:
+            assert rel_err(sd_new[k].float().cpu(), v.float().cpu()) < 2e-5, k
+        elif "num_batches_tracked" in k:
+            assert int(sd_new[k]) == int(v) == 3, k
