@@ -189,7 +189,7 @@ void plan(int B, int M, int N, int HW, int& spi, int& total, int& sps, int& S) {
     spi = (HW + TK - 1) / TK;
     total = B * spi;
     const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-    int want = (768 + tiles - 1) / tiles;
+    int want = (384 + tiles - 1) / tiles;
     if (want > (total + 3) / 4) want = (total + 3) / 4;      // at least ~4 steps per work item
     if (want < 1) want = 1;
     sps = (total + want - 1) / want;
