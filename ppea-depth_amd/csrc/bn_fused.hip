@@ -515,8 +515,16 @@ __global__ __launch_bounds__(TPB) void bn_apply_flat(const T* __restrict__ z1, c
     const long t = (long)blockIdx.x * TPB + threadIdx.x;
     if (t >= total8) return;
     const long i = t * V;
-    const long plane = i / HW;
-    const int n = (int)(plane / C), c = (int)(plane - (long)n * C);
+    // two 64-bit divisions per thread would cost more than the 8 elements of work: 32-bit whenever it fits
+    long plane;
+    int n, c;
+    if (total8 < (1L << 28)) {
+        const unsigned p32 = (unsigned)i / (unsigned)HW, n32 = p32 / (unsigned)C;
+        plane = p32; n = (int)n32; c = (int)(p32 - n32 * (unsigned)C);
+    } else {
+        plane = i / HW;
+        n = (int)(plane / C); c = (int)(plane - (long)n * C);
+    }
     const float a1 = b1.gamma[c] * b1.invstd[c], o1 = b1.beta[c] - b1.mean[c] * a1;
     float a2 = 0.f, o2 = 0.f;
     if (z2 != nullptr) { a2 = b2.gamma[c] * b2.invstd[c]; o2 = b2.beta[c] - b2.mean[c] * a2; }
@@ -548,8 +556,16 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_flat(const T* __restrict__ d
     const long t = (long)blockIdx.x * TPB + threadIdx.x;
     if (t >= total8) return;
     const long i = t * V;
-    const long plane = i / HW;
-    const int n = (int)(plane / C), c = (int)(plane - (long)n * C);
+    // two 64-bit divisions per thread would cost more than the 8 elements of work: 32-bit whenever it fits
+    long plane;
+    int n, c;
+    if (total8 < (1L << 28)) {
+        const unsigned p32 = (unsigned)i / (unsigned)HW, n32 = p32 / (unsigned)C;
+        plane = p32; n = (int)n32; c = (int)(p32 - n32 * (unsigned)C);
+    } else {
+        plane = i / HW;
+        n = (int)(plane / C); c = (int)(plane - (long)n * C);
+    }
     const float is1 = b1.invstd[c], mu1 = b1.mean[c];
     const float a1 = b1.gamma[c] * is1, o1 = b1.beta[c] - mu1 * a1;
     float is2 = 0.f, mu2 = 0.f, a2 = 0.f, o2 = 0.f;
