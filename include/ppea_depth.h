@@ -274,6 +274,36 @@ int ppea_cost_volume_reduce_f32(const float* cost, const float* bins, float* cos
                                 int B, int D, int h, int w, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm (+ReLU, + residual added before the activation) on channels_last data: the ResNet-18 pose
+ * trunk (networks/resnet_encoder.py:25-72).  The tensor is G consecutive sub-batches [G][P][C] (C contiguous,
+ * C / 8 a power of two <= 256), each normalised with its own statistics (per-pair statistics of a 2B pose batch).
+ *   forward : stats -> partial[G][slabs][2][C]; finalize -> stats[G][3][C] (mean | invstd | unbiased var),
+ *             ab[G][2][C] (y = a x + b), running statistics updated once per sub-batch in order;
+ *             apply -> y = act(a x + b + res), act 0 none / 1 ReLU
+ *   backward: bwd_reduce -> partial; bwd_finalize -> k[G][2][C], dgamma_dbeta[2][C]; bwd_apply -> dx, dres
+ * ---------------------------------------------------------------------------------------- */
+int ppea_nhwc_bn_slabs(int P, int C);
+int ppea_nhwc_bn_stats_f32(const void* x, float* partial, int P, int C, int G, void* stream);
+int ppea_nhwc_bn_stats_bf16(const void* x, float* partial, int P, int C, int G, void* stream);
+int ppea_nhwc_bn_finalize_f32(const float* partial, int P, int C, int G, const float* gamma, const float* beta,
+                              float eps, float momentum, float* stats, float* ab, float* running_mean,
+                              float* running_var, void* stream);
+int ppea_nhwc_bn_apply_f32(const void* x, const void* res, const float* ab, void* y, int P, int C, int G, int act,
+                           void* stream);
+int ppea_nhwc_bn_apply_bf16(const void* x, const void* res, const float* ab, void* y, int P, int C, int G, int act,
+                            void* stream);
+int ppea_nhwc_bn_bwd_reduce_f32(const void* x, const void* dy, const void* res, const float* stats, const float* ab,
+                                float* partial, int P, int C, int G, int act, void* stream);
+int ppea_nhwc_bn_bwd_reduce_bf16(const void* x, const void* dy, const void* res, const float* stats, const float* ab,
+                                 float* partial, int P, int C, int G, int act, void* stream);
+int ppea_nhwc_bn_bwd_finalize_f32(const float* partial, int P, int C, int G, float* k, float* dgamma_dbeta,
+                                  void* stream);
+int ppea_nhwc_bn_bwd_apply_f32(const void* x, const void* dy, const void* res, const float* stats, const float* ab,
+                               const float* k, void* dx, void* dres, int P, int C, int G, int act, void* stream);
+int ppea_nhwc_bn_bwd_apply_bf16(const void* x, const void* dy, const void* res, const float* stats, const float* ab,
+                                const float* k, void* dx, void* dres, int P, int C, int G, int act, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Bias + ELU of the decoders' ConvBlock (layers.py:103-116), NCHW: y = elu(z + bias[c]); backward dz = dy * elu'
  * (from the saved OUTPUT: elu' = 1 for y > 0 else y + 1) and partial[N*C][chunks] = per-plane-chunk sums of dz
  * (chunks = ppea_bias_elu_chunks(N, C, HW)); the bias gradient is their sum over N and chunks.

@@ -37,6 +37,17 @@ SIGNATURES = {
     "ppea_pwgrad_workspace_bytes": [_i, _i, _i, _i],
     "ppea_pwgrad_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ppea_pwgrad_ex_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "ppea_nhwc_bn_slabs": [_i, _i],
+    "ppea_nhwc_bn_stats_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "ppea_nhwc_bn_stats_bf16": [_vp, _vp, _i, _i, _i, _vp],
+    "ppea_nhwc_bn_finalize_f32": [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "ppea_nhwc_bn_apply_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_bn_apply_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_bn_bwd_reduce_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_bn_bwd_reduce_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_bn_bwd_finalize_f32": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "ppea_nhwc_bn_bwd_apply_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_bn_bwd_apply_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_bias_elu_chunks": [_i, _i, _i],
     "ppea_bias_elu_fwd_f32": [_vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "ppea_bias_elu_fwd_bf16": [_vp, _vp, _i, _vp, _i, _i, _i, _vp],

@@ -25,7 +25,7 @@ _ENC_CH = {"b": [128, 256, 512, 1024], "l": [192, 384, 768, 1536]}
 
 TWO_STREAMS = True
 BATCHED_POSES = True      # third (no_grad) pose pass replayed instead of recomputed (see _predict_poses_batched)
-POSE_ONE_BATCH = False
+POSE_ONE_BATCH = True      # both pairs as one 2B batch with per-pair BN statistics (needs the fused NHWC BN path)
 
 
 def _g(opt, name, default):

@@ -9,6 +9,7 @@ import torch.nn as nn
 
 
 CHANNELS_LAST = True
+FUSED_NHWC_BN = True      # pose-trunk BN + ReLU + residual on the channels_last HIP kernels (GroupBN.fused)
 
 
 class GroupBN(nn.BatchNorm2d):
@@ -20,6 +21,26 @@ class GroupBN(nn.BatchNorm2d):
     reference's no_grad pose pass for the matching frames) can be replayed as a running-statistics update."""
     groups = 1
     record = None           # None, or a list that receives (mean, invstd, count) per sub-batch
+
+    def fused(self, x, act=0, res=None):
+        """act(BN(x) + res) on the channels_last HIP kernels (per-sub-batch statistics, ReLU and the residual add in
+        the same pass); falls back to the composed ops when the tensor is not served."""
+        from .. import ops
+        if (FUSED_NHWC_BN and self.training and ops.nhwc_bn_supported(x, self.groups)
+                and (res is None or (res.shape == x.shape and res.dtype == x.dtype
+                                     and res.is_contiguous(memory_format=torch.channels_last)))):
+            y, stats = ops.nhwc_bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, act,
+                                       self.groups, self.eps, self.momentum)
+            self.num_batches_tracked += self.groups
+            if self.record is not None:
+                n = (x.shape[0] // self.groups) * x.shape[2] * x.shape[3]
+                for g in range(self.groups):
+                    self.record.append((stats[g, 0], stats[g, 1], n))
+            return y
+        y = self.forward(x)
+        if res is not None:
+            y = y + res
+        return torch.relu(y) if act == 1 else y
 
     def forward(self, x):
         if not self.training or (self.groups == 1 and self.record is None):
@@ -58,6 +79,10 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if FUSED_NHWC_BN and self.training and x.is_cuda:
+            identity = x if self.downsample is None else self.downsample[1].fused(self.downsample[0](x))
+            out = self.bn1.fused(self.conv1(x), 1)
+            return self.bn2.fused(self.conv2(out), 1, identity)
         identity = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
@@ -165,7 +190,8 @@ class ResnetEncoder(nn.Module):
             # trunk stays NHWC and no conv pays a layout round trip on its activations (the weights keep their
             # storage -- they are views into the optimizer's flat buffer -- and are re-laid-out per call, which is small)
             x = x.contiguous(memory_format=torch.channels_last)
-        self.features = [e.relu(e.bn1(e.conv1(x)))]
+        self.features = [e.bn1.fused(e.conv1(x), 1) if (FUSED_NHWC_BN and self.training and x.is_cuda)
+                         else e.relu(e.bn1(e.conv1(x)))]
         self.features.append(e.layer1(e.maxpool(self.features[-1])))
         self.features.append(e.layer2(self.features[-1]))
         self.features.append(e.layer3(self.features[-1]))

@@ -485,6 +485,75 @@ def bn_act_apply(z1, g1, b1, mean1, invstd1, z2=None, g2=None, b2=None, mean2=No
 
 
 # ---------------------------------------------------------------------------------------------
+# pose trunk: training-mode BN (+ReLU, + residual before the activation) on channels_last tensors, per sub-batch
+# ---------------------------------------------------------------------------------------------
+def _raw(t, byte_offset=0):
+    return None if t is None else _ct.c_void_p(t.data_ptr() + byte_offset)
+
+
+def nhwc_bn_supported(x, groups=1):
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (_F32, _BF16)):
+        return False
+    N, C = x.shape[0], x.shape[1]
+    ct = C // 8
+    return (C % 8 == 0 and 1 <= ct <= 256 and 256 % ct == 0 and N % groups == 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+class _NhwcBnAct(torch.autograd.Function):
+    """y = act(BN_g(x) + res) with separate batch statistics for each of `groups` consecutive sub-batches; the
+    running statistics are updated once per sub-batch, in order.  Returns (y, stats [G,3,C]) with stats =
+    mean | invstd | unbiased variance per sub-batch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, res, act, groups, eps, momentum):
+        N, C, H, W = x.shape
+        P = (N // groups) * H * W
+        sfx = _suffix(x)
+        dev = x.device
+        gam, bet = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        slabs = _abi.lib.ppea_nhwc_bn_slabs(P, C)
+        partial = torch.empty(groups * slabs * 2 * C, device=dev, dtype=_F32)
+        stats = torch.empty(groups, 3, C, device=dev, dtype=_F32)
+        ab = torch.empty(groups, 2, C, device=dev, dtype=_F32)
+        y = torch.empty_like(x)                             # preserves channels_last
+        st = stream_ptr()
+        call(f"ppea_nhwc_bn_stats_{sfx}", _raw(x), ptr(partial), P, C, groups, st)
+        call("ppea_nhwc_bn_finalize_f32", ptr(partial), P, C, groups, ptr(gam), ptr(bet), float(eps), float(momentum),
+             ptr(stats), ptr(ab), ptr(running_mean), ptr(running_var), st)
+        call(f"ppea_nhwc_bn_apply_{sfx}", _raw(x), _raw(res), ptr(ab), _raw(y), P, C, groups, int(act), st)
+        ctx.save_for_backward(x, res, stats, ab)
+        ctx.cfg = (int(act), int(groups), P, C, weight.dtype, bias.dtype)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _ds):
+        x, res, stats, ab = ctx.saved_tensors
+        act, groups, P, C, wdt, bdt = ctx.cfg
+        sfx = _suffix(x)
+        dev = x.device
+        dy = dy.contiguous(memory_format=torch.channels_last).to(x.dtype)
+        slabs = _abi.lib.ppea_nhwc_bn_slabs(P, C)
+        partial = torch.empty(groups * slabs * 2 * C, device=dev, dtype=_F32)
+        kk = torch.empty(groups, 2, C, device=dev, dtype=_F32)
+        tot = torch.empty(2, C, device=dev, dtype=_F32)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if res is not None else None
+        st = stream_ptr()
+        call(f"ppea_nhwc_bn_bwd_reduce_{sfx}", _raw(x), _raw(dy), _raw(res), ptr(stats), ptr(ab), ptr(partial),
+             P, C, groups, act, st)
+        call("ppea_nhwc_bn_bwd_finalize_f32", ptr(partial), P, C, groups, ptr(kk), ptr(tot), st)
+        call(f"ppea_nhwc_bn_bwd_apply_{sfx}", _raw(x), _raw(dy), _raw(res), ptr(stats), ptr(ab), ptr(kk),
+             _raw(dx), _raw(dres), P, C, groups, act, st)
+        return dx, tot[0].to(wdt), tot[1].to(bdt), None, None, dres, None, None, None, None
+
+
+def nhwc_bn_act(x, weight, bias, running_mean, running_var, res=None, act=ACT_NONE, groups=1, eps=1e-5, momentum=0.1):
+    return _NhwcBnAct.apply(x, weight, bias, running_mean, running_var, res, act, groups, eps, momentum)
+
+
+# ---------------------------------------------------------------------------------------------
 # A12 glue: bias + ELU of ConvBlock                                         layers.py:103-116
 # ---------------------------------------------------------------------------------------------
 class _BiasElu(torch.autograd.Function):

@@ -479,3 +479,46 @@ def test_bias_elu(device, dtype, shape):
     assert rel_err(y.float().cpu(), ref.detach()) < tol
     assert rel_err(zd.grad.float().cpu(), zr.grad) < max(tol, 1e-5)
     assert rel_err(bd.grad.cpu(), br.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("groups,act,res", [(1, 1, False), (2, 1, True), (2, 0, False), (1, 1, True)])
+@pytest.mark.parametrize("shape", [(4, 64, 12, 20), (2, 256, 3, 5), (6, 16, 7, 9)])
+def test_nhwc_bn_act(device, dtype, groups, act, res, shape):
+    """Pose-trunk BatchNorm on channels_last data: per-sub-batch statistics, ReLU and residual-before-activation in
+    the same pass, running statistics updated once per sub-batch in order; all gradients."""
+    import torch.nn.functional as F
+    from ppeadepth import ops
+    N, C, H, W = shape
+    g = _g(C + groups)
+    x = (torch.randn(shape, generator=g) * 1.5 + 0.3).to(dtype)
+    r = torch.randn(shape, generator=g).to(dtype)
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    go = torch.randn(shape, generator=g).to(dtype)
+    xr, rr = x.float().clone().requires_grad_(True), r.float().clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    outs = []
+    for xc, rc in zip(xr.chunk(groups, 0), rr.chunk(groups, 0)):
+        u = F.batch_norm(xc, rm, rv, wr, br, True, 0.1, 1e-5)
+        if res:
+            u = u + rc
+        outs.append(F.relu(u) if act == 1 else u)
+    ref = torch.cat(outs, 0)
+    (ref * go.float()).sum().backward()
+    cl = torch.channels_last
+    xd = x.to(device).contiguous(memory_format=cl).requires_grad_(True)
+    rd = r.to(device).contiguous(memory_format=cl).requires_grad_(True)
+    wd, bd = w.to(device).requires_grad_(True), b.to(device).requires_grad_(True)
+    rmd, rvd = torch.zeros(C, device=device), torch.ones(C, device=device)
+    assert ops.nhwc_bn_supported(xd, groups)
+    y, stats = ops.nhwc_bn_act(xd, wd, bd, rmd, rvd, rd if res else None, act, groups, 1e-5, 0.1)
+    assert y.is_contiguous(memory_format=cl)
+    (y.float() * go.to(device).float()).sum().backward()
+    tf, tb = (3e-5, 3e-4) if dtype == torch.float32 else (1e-2, 3e-2)
+    assert rel_err(y.float().cpu(), ref.detach()) < tf
+    assert rel_err(rmd.cpu(), rm) < 1e-5 and rel_err(rvd.cpu(), rv) < 1e-4
+    assert rel_err(xd.grad.float().cpu(), xr.grad) < tb
+    assert rel_err(wd.grad.cpu(), wr.grad) < tb and rel_err(bd.grad.cpu(), br.grad) < tb
+    if res:
+        assert rel_err(rd.grad.float().cpu(), rr.grad) < tb
