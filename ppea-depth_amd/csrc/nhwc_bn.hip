@@ -106,17 +106,33 @@ __global__ __launch_bounds__(TPB) void nhwc_reduce_kernel(const T* __restrict__ 
     }
 }
 
-__global__ void nhwc_bn_finalize_kernel(const float* __restrict__ partial, int slabs, int P, int C, int G,
-                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                        float momentum, float* __restrict__ stats /*[G][mean|invstd|unbiased var][C]*/,
-                                        float* __restrict__ ab /*[G][a|b][C]*/, float* __restrict__ running_mean,
-                                        float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// Finalize kernels: block = 16 channels x 16 slab lanes (a single thread walking 256 slab partials per channel is a
+// 60 us chain of dependent loads); the lanes' double-precision sums meet in LDS.
+constexpr int FC = 16, FL = 16;
+
+__device__ __forceinline__ void slab_sums(const float* __restrict__ pp, int slabs, int C, int c, int lane, double& s,
+                                          double& q, double (*sh)[FL][FC]) {
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int j = lane; j < slabs; j += FL) { a += pp[((long)j * 2) * C + c]; b += pp[((long)j * 2 + 1) * C + c]; }
+    __syncthreads();                                       // previous use of sh is over
+    sh[0][lane][threadIdx.x] = a; sh[1][lane][threadIdx.x] = b;
+    __syncthreads();
+    s = 0.0; q = 0.0;
+    if (lane == 0)
+        for (int l = 0; l < FL; ++l) { s += sh[0][l][threadIdx.x]; q += sh[1][l][threadIdx.x]; }
+}
+
+__global__ __launch_bounds__(FC * FL) void nhwc_bn_finalize_kernel(
+    const float* __restrict__ partial, int slabs, int P, int C, int G, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ stats /*[G][mean|invstd|unbiased var][C]*/,
+    float* __restrict__ ab /*[G][a|b][C]*/, float* __restrict__ running_mean, float* __restrict__ running_var) {
+    __shared__ double sh[2][FL][FC];
+    const int c = blockIdx.x * FC + threadIdx.x, lane = threadIdx.y;
     for (int g = 0; g < G; ++g) {                          // in order: each sub-batch updates the running statistics
-        const float* pp = partial + (long)g * slabs * 2 * C;
-        double s = 0.0, q = 0.0;
-        for (int j = 0; j < slabs; ++j) { s += pp[((long)j * 2) * C + c]; q += pp[((long)j * 2 + 1) * C + c]; }
+        double s, q;
+        slab_sums(partial + (long)g * slabs * 2 * C, slabs, C, c, lane, s, q, sh);
+        if (lane != 0 || c >= C) continue;
         const double mean = s / P;
         double var = q / P - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -133,20 +149,20 @@ __global__ void nhwc_bn_finalize_kernel(const float* __restrict__ partial, int s
     }
 }
 
-__global__ void nhwc_bn_bwd_finalize_kernel(const float* __restrict__ partial, int slabs, int P, int C, int G,
-                                            float* __restrict__ k /*[G][S1/P | S2/P][C]*/,
-                                            float* __restrict__ dgamma_dbeta /*[S2 | S1][C], summed over sub-batches*/) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(FC * FL) void nhwc_bn_bwd_finalize_kernel(
+    const float* __restrict__ partial, int slabs, int P, int C, int G, float* __restrict__ k /*[G][S1/P | S2/P][C]*/,
+    float* __restrict__ dgamma_dbeta /*[S2 | S1][C], summed over sub-batches*/) {
+    __shared__ double sh[2][FL][FC];
+    const int c = blockIdx.x * FC + threadIdx.x, lane = threadIdx.y;
     double t1 = 0.0, t2 = 0.0;
     for (int g = 0; g < G; ++g) {
-        const float* pp = partial + (long)g * slabs * 2 * C;
-        double s1 = 0.0, s2 = 0.0;
-        for (int j = 0; j < slabs; ++j) { s1 += pp[((long)j * 2) * C + c]; s2 += pp[((long)j * 2 + 1) * C + c]; }
+        double s1, s2;
+        slab_sums(partial + (long)g * slabs * 2 * C, slabs, C, c, lane, s1, s2, sh);
+        if (lane != 0 || c >= C) continue;
         k[g * 2 * C + c] = (float)(s1 / P); k[g * 2 * C + C + c] = (float)(s2 / P);
         t1 += s1; t2 += s2;
     }
-    dgamma_dbeta[c] = (float)t2; dgamma_dbeta[C + c] = (float)t1;
+    if (lane == 0 && c < C) { dgamma_dbeta[c] = (float)t2; dgamma_dbeta[C + c] = (float)t1; }
 }
 
 // FWD: y = act(a x + b + res).  BWD: dx = a (g - k1 - xhat k2), dres = g.
@@ -255,7 +271,7 @@ int ppea_nhwc_bn_finalize_f32(const float* partial, int P, int C, int G, const f
     if (!ok_shape(P, C) || G < 1) return PPEA_ERR_UNSUPPORTED;
     int rows;
     const int slabs = plan_slabs(P, C, rows);
-    hipLaunchKernelGGL(nhwc_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, slabs, P,
+    hipLaunchKernelGGL(nhwc_bn_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FC, FL), 0, (hipStream_t)stream, partial, slabs, P,
                        C, G, gamma, beta, eps, momentum, stats, ab, running_mean, running_var);
     return launch_status();
 }
@@ -281,7 +297,7 @@ int ppea_nhwc_bn_bwd_finalize_f32(const float* partial, int P, int C, int G, flo
     if (!ok_shape(P, C) || G < 1) return PPEA_ERR_UNSUPPORTED;
     int rows;
     const int slabs = plan_slabs(P, C, rows);
-    hipLaunchKernelGGL(nhwc_bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial,
+    hipLaunchKernelGGL(nhwc_bn_bwd_finalize_kernel, dim3((C + FC - 1) / FC), dim3(FC, FL), 0, (hipStream_t)stream, partial,
                        slabs, P, C, G, k, dgamma_dbeta);
     return launch_status();
 }
