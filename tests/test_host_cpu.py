@@ -203,3 +203,64 @@ def test_flat_gradient_allreduce_gloo_world2():
     for rank, ok_grad, ok_view, ok_bins, chunks in res:
         assert ok_grad and ok_view and ok_bins, (rank, ok_grad, ok_view, ok_bins)
         assert chunks >= 2
+
+
+def test_flat_grads_alignment_and_chunks():
+    """FlatGrads with aligned offsets (flat optimizer layout): views do not overlap, start on multiples of `align`,
+    chunk bounds fall on tensor boundaries and cover the buffer."""
+    from ppeadepth.dist import FlatGrads
+    ts = [torch.nn.Parameter(torch.randn(*s)) for s in [(3, 5), (130,), (7, 3, 3, 3), (1,), (256, 2)]]
+    fg = FlatGrads(ts, n_chunks=3, align=128)
+    assert all(o % 128 == 0 for o in fg.offsets) and fg.numel % 128 == 0
+    for t, v, o in zip(ts, fg.views, fg.offsets):
+        assert v.shape == t.shape and t.grad is v
+        assert v.data_ptr() == fg.flat.data_ptr() + 4 * o
+    ends = [o + t.numel() for t, o in zip(ts, fg.offsets)]
+    assert all(e <= n for e, n in zip(ends[:-1], fg.offsets[1:]))
+    assert fg.bounds[0] == 0 and fg.bounds[-1] == fg.numel and all(b in fg.offsets + [fg.numel] for b in fg.bounds)
+    for t in ts:                                           # gather: one multi-tensor copy per source dtype
+        t.grad = None
+    srcs = [torch.nn.Parameter(torch.zeros_like(t).to(torch.bfloat16 if i % 2 else torch.float32))
+            for i, t in enumerate(ts)]                     # bf16 working copies next to fp32 parameters
+    for i, s in enumerate(srcs):
+        s.grad = torch.full_like(s, float(i + 1))
+    srcs[3].grad = None
+    fg.gather(srcs)
+    for i, v in enumerate(fg.views):
+        assert torch.all(v == (0.0 if i == 3 else float(i + 1)))
+
+
+def test_pose_trunk_group_bn_and_pass_replay_cpu():
+    """GroupBN: a 2B batch with per-sub-batch statistics == two separate forward calls (outputs, running statistics,
+    counters); ResnetEncoder.batch_stats_since / replay_pass == running a third training-mode pass on the first
+    sub-batch again (reference repdepth.py:443-509 does exactly that under no_grad)."""
+    import copy
+    from ppeadepth.networks.resnet_encoder import ResnetEncoder
+    torch.manual_seed(0)
+    enc = ResnetEncoder(18, False, num_input_images=2).train()
+    ref = copy.deepcopy(enc)
+    xa, xb = torch.rand(2, 6, 32, 64), torch.rand(2, 6, 32, 64)
+    fa, fb = ref(xa)[-1], ref(xb)[-1]
+    with torch.no_grad():
+        ref(xa)                                            # third pass on the first pair
+    # (1) one 2B batch with two groups, statistics of the first group recorded and replayed
+    one = copy.deepcopy(enc)
+    f = one(torch.cat([xa, xb], 0), groups=2, record=True)[-1]
+    assert rel_err(f[:2], fa) < 1e-5 and rel_err(f[2:], fb) < 1e-5
+    for bn, mean, invstd, count in one.recorded:
+        bn.replay_update(mean, invstd, count)
+    # (2) two passes + replay from the running-statistics delta of the first
+    two = copy.deepcopy(enc)
+    snap = two.snapshot_running()
+    ga = two(xa)[-1]
+    stats = two.batch_stats_since(snap)
+    gb = two(xb)[-1]
+    two.replay_pass(stats)
+    assert rel_err(ga, fa) < 1e-6 and rel_err(gb, fb) < 1e-6
+    sd_ref = ref.state_dict()
+    for name, cand in (("one batch", one.state_dict()), ("delta replay", two.state_dict())):
+        for k, v in sd_ref.items():
+            if "running" in k:
+                assert rel_err(cand[k], v) < 2e-4, (name, k)
+            elif "num_batches_tracked" in k:
+                assert int(cand[k]) == int(v) == 3, (name, k)
