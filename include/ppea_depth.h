@@ -314,6 +314,18 @@ int ppea_bias_elu_fwd_bf16(const void* z, const void* bias, int bias_bf16, void*
 int ppea_bias_elu_bwd_f32(const void* dy, const void* y, void* dz, float* partial, int N, int C, int HW, void* stream);
 int ppea_bias_elu_bwd_bf16(const void* dy, const void* y, void* dz, float* partial, int N, int C, int HW, void* stream);
 
+/* channels_last versions of the decoder passes (x [B][H][W][C], C % 8 == 0; bias_elu: C / 8 a power of two <= 256):
+ * the decoders hand the library's NHWC-native convolutions NHWC activations. */
+int ppea_nhwc_reflect_pad1_fwd_f32(const void* x, void* out, int B, int H, int W, int C, void* stream);
+int ppea_nhwc_reflect_pad1_fwd_bf16(const void* x, void* out, int B, int H, int W, int C, void* stream);
+int ppea_nhwc_reflect_pad1_bwd_f32(const void* dout, void* dx, int B, int H, int W, int C, void* stream);
+int ppea_nhwc_reflect_pad1_bwd_bf16(const void* dout, void* dx, int B, int H, int W, int C, void* stream);
+int ppea_nhwc_bias_elu_slabs(int P, int C);
+int ppea_nhwc_bias_elu_fwd_f32(const void* z, const void* bias, int bias_bf16, void* y, int P, int C, void* stream);
+int ppea_nhwc_bias_elu_fwd_bf16(const void* z, const void* bias, int bias_bf16, void* y, int P, int C, void* stream);
+int ppea_nhwc_bias_elu_bwd_f32(const void* dy, const void* y, void* dz, float* partial, int P, int C, void* stream);
+int ppea_nhwc_bias_elu_bwd_bf16(const void* dy, const void* y, void* dz, float* partial, int P, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimizer step (trainer.py:350, torch.optim.Adam with the reference's defaults) over ONE flat fp32 buffer
  * holding every trainable tensor: p, g, m, v fp32 [n]; w16 (may be NULL) = bf16 working copy of p[0, n_lo);

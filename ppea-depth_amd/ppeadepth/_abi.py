@@ -53,6 +53,15 @@ SIGNATURES = {
     "ppea_bias_elu_fwd_bf16": [_vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "ppea_bias_elu_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ppea_bias_elu_bwd_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ppea_nhwc_reflect_pad1_fwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_reflect_pad1_fwd_bf16": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_reflect_pad1_bwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_reflect_pad1_bwd_bf16": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_bias_elu_slabs": [_i, _i],
+    "ppea_nhwc_bias_elu_fwd_f32": [_vp, _vp, _i, _vp, _i, _i, _vp],
+    "ppea_nhwc_bias_elu_fwd_bf16": [_vp, _vp, _i, _vp, _i, _i, _vp],
+    "ppea_nhwc_bias_elu_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "ppea_nhwc_bias_elu_bwd_bf16": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "ppea_adam_flat_f32": [_vp, _vp, _vp, _vp, _vp, ctypes.c_long, ctypes.c_long, _vp, _f, _f, _f, _vp],
     "ppea_tapsum_fwd_bf16": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_tapsum_bwd_bf16": [_vp, _vp, _i, _i, _i, _i, _vp],

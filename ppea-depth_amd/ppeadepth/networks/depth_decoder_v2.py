@@ -7,6 +7,9 @@ import torch.nn.functional as F
 from ..layers import ConvBlock, Conv3x3, upsample
 
 
+NHWC = True
+
+
 class Adapter(nn.Module):
     """dec.py:19-55: Linear(C_in -> hidden) -> GELU -> Linear(hidden -> C_out), D_fc2 zero-initialised."""
 
@@ -59,6 +62,11 @@ class DepthDecoderV2(nn.Module):
 
     def forward(self, input_features):
         self.outputs = {}
+        if NHWC and input_features[-1].is_cuda and not self.dc:
+            # the decoder's 3x3 convolutions run on the library's NHWC-native implicit-GEMM kernels: hand them
+            # channels_last activations once here (pad / bias + ELU have channels_last kernels, upsample and concat keep
+            # the format) instead of a layout round trip around every convolution
+            input_features = [f.contiguous(memory_format=torch.channels_last) for f in input_features]
         x = input_features[-1]
         adpt_out = None
         if self.dc:

@@ -556,6 +556,40 @@ def nhwc_bn_act(x, weight, bias, running_mean, running_var, res=None, act=ACT_NO
 # ---------------------------------------------------------------------------------------------
 # A12 glue: bias + ELU of ConvBlock                                         layers.py:103-116
 # ---------------------------------------------------------------------------------------------
+def _is_nhwc(t):
+    """channels_last storage (and not at the same time NCHW-contiguous, as C == 1 or H == W == 1 would be)."""
+    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def _nhwc_c_ok(C):
+    ct = C // 8
+    return C % 8 == 0 and 1 <= ct <= 256 and 256 % ct == 0
+
+
+class _BiasEluNhwc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, bias):
+        N, C, H, W = z.shape
+        y = torch.empty_like(z)
+        bp, bflag = _bias_arg(bias.detach().contiguous())
+        call(f"ppea_nhwc_bias_elu_fwd_{_suffix(z)}", _raw(z), bp, bflag, _raw(y), N * H * W, C, stream_ptr())
+        ctx.save_for_backward(y)
+        ctx.bdt = bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        N, C, H, W = y.shape
+        dy = dy.contiguous(memory_format=torch.channels_last).to(y.dtype)
+        slabs = _abi.lib.ppea_nhwc_bias_elu_slabs(N * H * W, C)
+        partial = torch.empty(slabs, C, device=y.device, dtype=_F32)
+        dz = torch.empty_like(y)
+        call(f"ppea_nhwc_bias_elu_bwd_{_suffix(y)}", _raw(dy), _raw(y), _raw(dz), ptr(partial), N * H * W, C,
+             stream_ptr())
+        return dz, partial.sum(0).to(ctx.bdt)
+
+
 class _BiasElu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, bias):
@@ -583,13 +617,34 @@ class _BiasElu(torch.autograd.Function):
 
 
 def bias_elu(z, bias):
-    """elu(z + bias[None, :, None, None]) in one pass; the bias gradient comes out of the backward pass."""
+    """elu(z + bias[None, :, None, None]) in one pass; the bias gradient comes out of the backward pass.
+    NCHW or channels_last input (output in the same format)."""
+    if _is_nhwc(z) and _nhwc_c_ok(z.shape[1]):
+        return _BiasEluNhwc.apply(z, bias)
     return _BiasElu.apply(z, bias)
 
 
 # ---------------------------------------------------------------------------------------------
 # A12 glue: ReflectionPad2d(1)                                            layers.py:119-135
 # ---------------------------------------------------------------------------------------------
+class _ReflectPad1Nhwc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        out = torch.empty(B, C, H + 2, W + 2, device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+        call(f"ppea_nhwc_reflect_pad1_fwd_{_suffix(x)}", _raw(x), _raw(out), B, H, W, C, stream_ptr())
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C, H, W = ctx.shape
+        dout = dout.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty(B, C, H, W, device=dout.device, dtype=dout.dtype, memory_format=torch.channels_last)
+        call(f"ppea_nhwc_reflect_pad1_bwd_{_suffix(dout)}", _raw(dout), _raw(dx), B, H, W, C, stream_ptr())
+        return dx
+
+
 class _ReflectPad1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -612,6 +667,8 @@ class _ReflectPad1(torch.autograd.Function):
 def reflect_pad1(x):
     if x.shape[-1] < 3 or x.shape[-2] < 3 or x.dtype not in (_F32, _BF16) or not x.is_cuda:
         return torch.nn.functional.pad(x, (1, 1, 1, 1), mode="reflect")
+    if _is_nhwc(x) and x.shape[1] % 8 == 0:
+        return _ReflectPad1Nhwc.apply(x)
     return _ReflectPad1.apply(x)
 
 

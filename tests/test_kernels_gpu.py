@@ -522,3 +522,30 @@ def test_nhwc_bn_act(device, dtype, groups, act, res, shape):
     assert rel_err(wd.grad.cpu(), wr.grad) < tb and rel_err(bd.grad.cpu(), br.grad) < tb
     if res:
         assert rel_err(rd.grad.float().cpu(), rr.grad) < tb
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 32, 7, 9), (1, 8, 3, 3), (2, 64, 24, 80), (1, 16, 3, 11)])
+def test_decoder_passes_channels_last(device, dtype, shape):
+    """ReflectionPad2d(1) and bias + ELU on channels_last tensors (decoder in NHWC): values, format and gradients."""
+    import torch.nn.functional as F
+    from ppeadepth import ops
+    g = _g(shape[1] + shape[2])
+    cl = torch.channels_last
+    x = torch.randn(shape, generator=g).to(dtype)
+    b = torch.randn(shape[1], generator=g)
+    xr, br = x.float().clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.elu(F.pad(xr, (1, 1, 1, 1), mode="reflect") + br.view(1, -1, 1, 1))
+    go = torch.randn(ref.shape, generator=g).to(dtype)
+    (ref * go.float()).sum().backward()
+    xd = x.to(device).contiguous(memory_format=cl).requires_grad_(True)
+    bd = b.to(device).requires_grad_(True)
+    p = ops.reflect_pad1(xd)
+    assert p.is_contiguous(memory_format=cl) and p.shape == ref.shape
+    y = ops.bias_elu(p, bd)
+    assert y.is_contiguous(memory_format=cl)
+    (y.float() * go.to(device).contiguous(memory_format=cl).float()).sum().backward()
+    tol = 3e-6 if dtype == torch.float32 else 1e-2
+    assert rel_err(y.float().cpu(), ref.detach()) < tol
+    assert rel_err(xd.grad.float().cpu(), xr.grad) < max(tol, 2e-5)
+    assert rel_err(bd.grad.cpu(), br.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
