@@ -277,14 +277,23 @@ class TrainEngine:
         self.static_out = (outputs, losses)
 
     def replay(self, inputs=None):
+        """Copy the new batch into the graph's static inputs and replay.  Everything -- the input copies, the
+        augmentation draws and the graph -- is enqueued on the step stream, ordered after the caller's stream (which
+        produced `inputs`); the caller's stream then waits for the step, so reading the returned tensors (or feeding
+        the next batch) from it is ordered without a device-wide synchronize."""
         from . import rng
-        if inputs is not None:
-            for k, v in inputs.items():
-                if k in self.static_inputs and v.data_ptr() != self.static_inputs[k].data_ptr():
-                    self.static_inputs[k].copy_(v, non_blocking=True)
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
+            if inputs is not None:
+                for k, v in inputs.items():
+                    if k in self.static_inputs and v.data_ptr() != self.static_inputs[k].data_ptr():
+                        self.static_inputs[k].copy_(v, non_blocking=True)
+                        if v.is_cuda:
+                            v.record_stream(self.stream)
             rng.refill_aug_buffer()
             self.graph.replay()
+        cur.wait_stream(self.stream)
         self.trainer.step += 1
         return self.static_out
 
@@ -318,8 +327,14 @@ class TrainEngine:
         if self.stream is None:
             outputs, losses = self._step_body(inputs)
         else:
-            self.stream.wait_stream(torch.cuda.current_stream())
+            cur = torch.cuda.current_stream()
+            self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):
                 outputs, losses = self._step_body(inputs)
+            cur.wait_stream(self.stream)          # results are consumed on the caller's stream
+            for d in (outputs, losses):
+                for v in d.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(cur)
         self.trainer.step += 1
         return outputs, losses

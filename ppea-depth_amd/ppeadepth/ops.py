@@ -54,7 +54,10 @@ def _packed_filter(w, flip):
     another model's weight."""
     key = (id(w), int(flip))
     ver = w._version
-    hit = _PACK_CACHE.get(key)
+    # A trainable filter (--fullft_reb) is updated by the flat Adam kernel through raw pointers, which does not
+    # bump `_version`: pack it on every use (the pack launch is then part of the captured step as well).
+    cacheable = not w.requires_grad
+    hit = _PACK_CACHE.get(key) if cacheable else None
     if hit is not None and hit[3]() is w and hit[0] == ver and hit[2] == tuple(w.shape):
         return hit[1]
     C, K = w.shape[0], w.shape[-1]
@@ -62,7 +65,8 @@ def _packed_filter(w, flip):
     buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     wf = w.detach().to(_F32).contiguous()
     call("ppea_dwconv_lk_pack_bf16", ptr(wf), ptr(buf), C, K, int(flip), stream_ptr())
-    _PACK_CACHE[key] = (ver, buf, tuple(w.shape), weakref.ref(w, lambda _r, k=key: _PACK_CACHE.pop(k, None)))
+    if cacheable:
+        _PACK_CACHE[key] = (ver, buf, tuple(w.shape), weakref.ref(w, lambda _r, k=key: _PACK_CACHE.pop(k, None)))
     return buf
 
 

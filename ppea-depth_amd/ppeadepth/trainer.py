@@ -20,8 +20,11 @@ from .layers import disp_to_depth
 
 
 class DepthBins:
-    """trainer.py:41-69 -- EMA(0.99) tracker of the teacher's depth range.  State stays on the
-    device; with several ranks min/max are reduced like torchmetrics does (dist_reduce_fx)."""
+    """trainer.py:41-69 -- EMA(0.99) tracker of the teacher's depth range.  The state is two persistent
+    0-dim device tensors that are only ever updated IN PLACE: a captured step graph reads and writes the
+    same storage on every replay, so the adaptive bins keep moving under hipGraph replay exactly as they do
+    in eager steps.  With several ranks `compute()` reduces min/max like torchmetrics does
+    (dist_reduce_fx = "min" / "max") without writing the reduced values back."""
 
     def __init__(self, opt_min_depth, device="cpu"):
         self.min_depth = torch.tensor(0.1, device=device)
@@ -41,11 +44,15 @@ class DepthBins:
         mx = d.amax((-1, -2)).mean()
         mn = torch.clamp(mn * 0.9, min=self.opt_min_depth)
         mx = mx * 1.1
-        self.max_depth = self.max_depth * 0.99 + mx * 0.01
-        self.min_depth = self.min_depth * 0.99 + mn * 0.01
+        # same association as the reference (state * 0.99 + new * 0.01), written into the persistent tensors
+        self.max_depth.mul_(0.99).add_(mx * 0.01)
+        self.min_depth.mul_(0.99).add_(mn * 0.01)
 
+    @torch.no_grad()
     def load(self, min_depth, max_depth):
-        self.min_depth, self.max_depth = min_depth, max_depth
+        self.min_depth.copy_(torch.as_tensor(min_depth).reshape(()))
+        self.max_depth.copy_(torch.as_tensor(max_depth).reshape(()))
+        self.updated = True
 
     def compute(self):
         mn, mx = self.min_depth.float(), self.max_depth.float()
@@ -94,9 +101,12 @@ class Trainer:
     # ---- trainer.py:420-472 -----------------------------------------------------------------------
     def process_batch(self, inputs, is_train=False):
         tracker = self.depth_bin_tracker
-        if getattr(self.opt, "notadabins", False) or not tracker.updated:
+        if getattr(self.opt, "notadabins", False):
             min_depth, max_depth = tracker.min_depth, tracker.max_depth
         else:
+            # trainer.py:425-431 reads the raw state before the first update and compute() afterwards.  Before the
+            # first update the state is the same constant on every rank, so compute() returns the raw state there
+            # too: no host-side `updated` branch, which a captured step graph would freeze at capture time.
             min_depth, max_depth = tracker.compute()
         self._identity_cache = None
         if self.amp_dtype is not None:

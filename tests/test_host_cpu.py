@@ -128,6 +128,23 @@ def test_depth_bins_tracker(golden):
         assert rel_err(mn, g["mins"][i]) < 1e-6 and rel_err(mx, g["maxs"][i]) < 1e-6
 
 
+def test_depth_bins_state_is_updated_in_place(golden):
+    """A captured step graph reads and writes the tracker through fixed addresses: update()/load() must never rebind
+    the state tensors (the bins were frozen under hipGraph replay)."""
+    from ppeadepth.trainer import DepthBins
+    g = golden("depth_bins")
+    tr = DepthBins(0.1)
+    mn_t, mx_t = tr.min_depth, tr.max_depth
+    ptrs = (mn_t.data_ptr(), mx_t.data_ptr())
+    for i in range(g["depths"].shape[0]):
+        tr.update(g["depths"][i])
+    assert tr.min_depth is mn_t and tr.max_depth is mx_t
+    assert (tr.min_depth.data_ptr(), tr.max_depth.data_ptr()) == ptrs
+    assert rel_err(mn_t, g["mins"][-1]) < 1e-6 and rel_err(mx_t, g["maxs"][-1]) < 1e-6
+    tr.load(torch.tensor(0.3), torch.tensor([7.0]))
+    assert tr.min_depth is mn_t and float(mn_t) == pytest.approx(0.3) and float(mx_t) == pytest.approx(7.0)
+
+
 def test_geometry_helpers_match_reference_golden(golden):
     from ppeadepth import layers
     g = golden("layers_geometry")

@@ -134,6 +134,48 @@ def test_dwconv_linearity_full_size(device):
     assert torch.equal(patch, wb[:, 0].flip(-1, -2))
 
 
+def test_dwconv_bf16_mfma_full_size_vs_fp32_kernel(device):
+    """The BENCHMARKED kernel at the benchmarked shape: bf16 [12,128,48,160] through `dwconv_mfma_kernel<31,5,*,5>`
+    (forward and data gradient) against the fp32 vector kernel `dwconv_lk_kernel` on the same bf16-rounded values.
+    Tolerance: both accumulate in fp32; the MFMA path rounds its result to bf16 once (2^-8 relative) and sums the
+    961 taps in a different order (a few 1e-4 of the output scale)."""
+    ops = _ops()
+    N, C, H, W, K = 12, 128, 48, 160, 31
+    g = torch.Generator(device="cpu").manual_seed(21)
+    wb = (torch.randn(C, 1, K, K, generator=g) / K).bfloat16().float().to(device)
+    ws = (torch.randn(C, 1, 5, 5, generator=g) / 5).bfloat16().float().to(device)
+    x = torch.randn(N, C, H, W, generator=g).bfloat16().to(device)
+    gb = torch.randn(N, C, H, W, generator=g).bfloat16().to(device)
+    gs = torch.randn(N, C, H, W, generator=g).bfloat16().to(device)
+
+    def run(xin, gbin, gsin):
+        xin = xin.clone().requires_grad_(True)
+        yb, ys = ops.dwconv_lk(xin, wb, ws)
+        torch.autograd.backward([yb, ys], [gbin, gsin])
+        return yb, ys, xin.grad
+
+    yb16, ys16, dx16 = run(x, gb, gs)
+    assert yb16.dtype == torch.bfloat16 and dx16.dtype == torch.bfloat16
+    yb32, ys32, dx32 = run(x.float(), gb.float(), gs.float())
+    for a, b in ((yb16, yb32), (ys16, ys32), (dx16, dx32)):
+        a = a.float()
+        bad = (a - b).abs() > b.abs() * 2 ** -7 + b.abs().max() * 1e-3
+        assert not bool(bad.any()), float((a - b).abs().max() / b.abs().max())
+
+
+def test_dwconv_trainable_filter_is_repacked(device):
+    """--fullft_reb: the flat Adam kernel updates filters through raw pointers (no `_version` bump).  A trainable
+    filter must therefore never be served from the packed-image cache."""
+    ops = _ops()
+    C, K = 8, 13
+    w = torch.nn.Parameter((torch.randn(C, 1, K, K, generator=_g(1)) / K).to(device))
+    x = torch.randn(2, C, 6, 20, generator=_g(2)).bfloat16().to(device)
+    y1, _ = ops.dwconv_lk(x, w, None)
+    w.data.mul_(2.0)                               # `.data`: storage changes, version counter does not
+    y2, _ = ops.dwconv_lk(x, w, None)
+    assert rel_err(y2.float(), 2.0 * y1.float()) < 2 ** -7
+
+
 # ---------------------------------------------------------------------------------------------
 def test_backproject_project_golden(device, golden):
     ops = _ops()
