@@ -242,7 +242,13 @@ GRAD_KEYS = [
 ]
 
 
-def gen_e2e(name, B, H, W, extra=(), stride=1, seed=1):
+DC_GRAD_KEYS = [k for k in GRAD_KEYS if not k.startswith(("depth.", "mono_depth."))] + [
+    "depth.adapter.D_fc1.weight", "depth.adapter.D_fc2.weight", "depth.adapter.D_fc2.bias",
+    "depth.deconv_adpt.weight", "depth.deconv_adpt.bias", "mono_depth.adapter.D_fc1.bias",
+    "mono_depth.deconv_adpt.weight"]
+
+
+def gen_e2e(name, B, H, W, extra=(), stride=1, seed=1, grad_keys=None, intrinsics="kitti"):
     """Unmodified Trainer.process_batch + backward of the reference (config-1 style)."""
     opt = rh.parse_options(["--height", str(H), "--width", str(W), "--batch_size", str(B)]
                            + list(extra))
@@ -251,10 +257,12 @@ def gen_e2e(name, B, H, W, extra=(), stride=1, seed=1):
     with rh.scratch_cwd():
         from ppeadepth import networks
         model = networks.RepDepth(opt)
+    if opt.dc:
+        model.dc_ft_init()                 # Trainer.__init__, trainer.py:158-161 (Stage-2: decoder adapter only)
     model.train()
     synth.fill_state_dict(model)
     tr = rh.build_reference_trainer(opt, model)
-    inputs = synth.make_inputs(B, H, W)
+    inputs = synth.make_inputs(B, H, W, intrinsics=intrinsics)
     torch.manual_seed(seed)
     random.seed(seed)
     outputs, losses = tr.process_batch(inputs, True)
@@ -272,7 +280,7 @@ def gen_e2e(name, B, H, W, extra=(), stride=1, seed=1):
         arrays[key] = v
     arrays["in:relative_pose|-1"] = inputs[("relative_pose", -1)]
     params = dict(model.named_parameters())
-    for k in GRAD_KEYS:
+    for k in (grad_keys or GRAD_KEYS):
         g = params[k].grad
         arrays["grad_sum:" + k] = g.double().sum().float()
         arrays["grad_abs:" + k] = g.double().abs().sum().float()
@@ -316,6 +324,12 @@ GENERATORS = {
     "e2e_small": lambda: gen_e2e("e2e_small", 2, 64, 96),
     "e2e_small_ckpt": lambda: gen_e2e("e2e_small_ckpt", 2, 64, 96, extra=["--use_checkpoint"]),
     "e2e_full": lambda: gen_e2e("e2e_full", 2, 192, 640, stride=8),
+    # BASELINE config 4's model (RepLKNet-31L: 1.5x channels) at a reduced frame size
+    "e2e_l": lambda: gen_e2e("e2e_l", 2, 64, 96, extra=["--rep_size", "l"], stride=2),
+    # BASELINE config 5 (Stage-2 `--dc`: decoder adapter trained, decoder frozen) at the reference-faithful
+    # Cityscapes size 192x512 (trainer.py:90-93) with Cityscapes-like intrinsics
+    "e2e_dc": lambda: gen_e2e("e2e_dc", 2, 192, 512, extra=["--dc"], stride=8, grad_keys=DC_GRAD_KEYS,
+                              intrinsics="cityscapes"),
 }
 
 

@@ -90,7 +90,19 @@ def _resnet18(spec, p):
     spec[p + ".fc.bias"] = ((1000,), F32)
 
 
-def state_spec(rep_size="b", num_depth_bins=96):
+def _decoder_adapter(spec, p, ch, ratio=0.25):
+    """Stage-2 `--dc` additions of dc_ft_init design 1 (repdepth.py:199-203; depth_decoder_v2.py:19-30)."""
+    cin, cout = ch[3] + ch[0], ch[0] // 4
+    hid = int((cin + cout) / 2 * ratio)
+    spec[f"{p}.adapter.D_fc1.weight"] = ((hid, cin), F32)
+    spec[f"{p}.adapter.D_fc1.bias"] = ((hid,), F32)
+    spec[f"{p}.adapter.D_fc2.weight"] = ((cout, hid), F32)
+    spec[f"{p}.adapter.D_fc2.bias"] = ((cout,), F32)
+    spec[f"{p}.deconv_adpt.weight"] = ((cout, cout, 3, 3), F32)
+    spec[f"{p}.deconv_adpt.bias"] = ((cout,), F32)
+
+
+def state_spec(rep_size="b", num_depth_bins=96, dc=False):
     ch = CHANNELS[rep_size]
     spec = {}
     _replknet(spec, "encoder.replk", ch)
@@ -103,4 +115,7 @@ def state_spec(rep_size="b", num_depth_bins=96):
     for i, (co, ci, k) in enumerate(((256, 512, 1), (256, 256, 3), (256, 256, 3), (12, 256, 1))):
         spec[f"pose.net.{i}.weight"] = ((co, ci, k, k), F32)
         spec[f"pose.net.{i}.bias"] = ((co,), F32)
+    if dc:
+        _decoder_adapter(spec, "depth", ch)
+        _decoder_adapter(spec, "mono_depth", ch)
     return spec

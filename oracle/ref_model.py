@@ -25,6 +25,8 @@ DROP_PATH_RATE = 0.3                  # replk_matching_adapter.py:62, repdepth.p
 def trainable(name: str, opt) -> bool:
     """Freeze rule by parameter-name substring (repdepth.py:47-50, 121-124), Stage-1."""
     top = name.split(".")[0]
+    if getattr(opt, "dc", False) and top in ("depth", "mono_depth"):
+        return "adpt" in name or "adapter" in name        # dc_ft_init, repdepth.py:255-262
     if top == "encoder":
         return any(s in name for s in ("adpt", "adapter", "reduce", "bn"))
     if top == "mono_encoder":
@@ -162,6 +164,19 @@ class RefRepDepth:
     def depth_decoder(self, feats, p):
         up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")  # noqa: E731
         x = feats[-1]
+        adpt = None
+        if getattr(self.opt, "dc", False):
+            # Stage-2 decoder adapter, design 1 (depth_decoder_v2.py:19-55, 178-182): token-wise
+            # Linear -> GELU -> Linear over cat(feat0, nearest x8 of feat3), then ConvTranspose2d(3, s2, p1, op1)
+            sd = self.sd
+            t = torch.cat([feats[0], F.interpolate(x, scale_factor=8, mode="nearest")], 1)
+            B, C, H, W = t.shape
+            t = t.flatten(2).permute(0, 2, 1)
+            t = F.linear(F.gelu(F.linear(t, sd[p + ".adapter.D_fc1.weight"], sd[p + ".adapter.D_fc1.bias"])),
+                         sd[p + ".adapter.D_fc2.weight"], sd[p + ".adapter.D_fc2.bias"])
+            t = t.permute(0, 2, 1).reshape(B, -1, H, W)
+            adpt = F.conv_transpose2d(t, sd[p + ".deconv_adpt.weight"], sd[p + ".deconv_adpt.bias"], stride=2,
+                                      padding=1, output_padding=1)
         for i in range(4):
             x = F.elu(self._conv3x3(x, f"{p}.upconvs_0.{i}.conv"))
             x = up(x)
@@ -170,6 +185,8 @@ class RefRepDepth:
             x = F.elu(self._conv3x3(x, f"{p}.upconvs_1.{i}.conv"))
         x = up(F.elu(self._conv3x3(x, f"{p}.upconvs_0.4.conv")))
         x = F.elu(self._conv3x3(x, f"{p}.upconvs_1.4.conv"))
+        if adpt is not None:                                  # depth_decoder_v2.py:230-233
+            x = x + F.interpolate(adpt, scale_factor=2)
         return torch.sigmoid(self._conv3x3(x, f"{p}.disp_convs.0"))
 
     # ----- pose network (resnet_encoder.py:397-409, pose_decoder.py:33-52) -----

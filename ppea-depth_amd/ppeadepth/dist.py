@@ -255,26 +255,76 @@ class TrainEngine:
     # launch); the captured graph replays the same launches (ours and the library ones) from the GPU's
     # command processor.  Shapes are static; the only per-step host inputs -- the batch and the matching
     # augmentation draws -- are copied into static buffers before each replay.
-    def capture(self, inputs, warmup=3):
+    def capture(self, inputs, warmup=3, restore_state=False):
+        """Warm up with `warmup` eager steps on a static copy of `inputs`, then record the step into a hipGraph.
+        restore_state: put model / optimizer / tracker state back to what it was before the warm-up steps (in place,
+        so the graph's addresses stay valid) -- the first replay is then step 1 of the run."""
         from . import rng
         dev = self.params[0].device
+        snap = self.snapshot() if restore_state else None
         self.static_inputs = {k: v.clone() for k, v in inputs.items()}
         B = self.static_inputs[("color", 0, 0)].shape[0]
         rng.set_aug_buffer(torch.zeros(B, device=dev))
+        reference_rng = rng.get_mode() == "reference"
+        warmup = max(int(warmup), 1)
         import gc
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
-            for _ in range(warmup):
+            for i in range(warmup):
                 rng.refill_aug_buffer()
+                if reference_rng and i == warmup - 1:
+                    rng.static_begin_record()      # this step's host draws become the graph's static draw buffers
                 self._step_body(dict(self.static_inputs))
+                if reference_rng and i == warmup - 1:
+                    rng.static_end_record()
         torch.cuda.synchronize()
         gc.collect()                        # drop autograd graphs of earlier steps before capturing
         self.graph = torch.cuda.CUDAGraph()
         rng.refill_aug_buffer()
+        rng.static_rewind()
         torch.cuda.synchronize()
         with torch.cuda.graph(self.graph, stream=self.stream):
             outputs, losses = self._step_body(dict(self.static_inputs))
         self.static_out = (outputs, losses)
+        if snap is not None:
+            self.restore(snap)
+
+    # ---- in-memory state snapshot (model, optimizer, depth-bin tracker) ----------------------------------
+    def _state_tensors(self):
+        model = self.trainer._module()
+        ts = [v for v in model.state_dict().values()]
+        if self.flat_adam:
+            ts += [self.P, self.M, self.V, self.adam_state, self.flat.flat]
+            if self.n_lo:
+                ts.append(self.W16)
+        tr = self.trainer.depth_bin_tracker
+        ts += [tr.min_depth, tr.max_depth]
+        return ts
+
+    @torch.no_grad()
+    def snapshot(self):
+        if not self.flat_adam:
+            raise NotImplementedError("snapshot/restore covers the flat-optimizer layout (the GPU path)")
+        torch.cuda.synchronize()
+        return [t.detach().clone() for t in self._state_tensors()], self.trainer.depth_bin_tracker.updated
+
+    @torch.no_grad()
+    def restore(self, snap):
+        """Copy a snapshot back IN PLACE (addresses captured in the step graph stay valid)."""
+        torch.cuda.synchronize()
+        for t, s in zip(self._state_tensors(), snap[0]):
+            t.copy_(s)
+        self.trainer.depth_bin_tracker.updated = snap[1]
+        torch.cuda.synchronize()
+
+    def named_grads(self):
+        """name -> fp32 gradient of this step for every trainable parameter (the flat buffer's views)."""
+        model = self.trainer._module()
+        names = {id(p): n for n, p in model.named_parameters()}
+        if self.flat is not None:
+            return {names[id(p)]: v for p, v in zip(self.params, self.flat.views)}
+        return {names[id(p)]: (self.masters[id(p)].grad if self.masters and id(p) in self.masters else p.grad)
+                for p in self.params}
 
     def replay(self, inputs=None):
         """Copy the new batch into the graph's static inputs and replay.  Everything -- the input copies, the
@@ -292,6 +342,7 @@ class TrainEngine:
                         if v.is_cuda:
                             v.record_stream(self.stream)
             rng.refill_aug_buffer()
+            rng.refill_static()             # reference-order DropPath / tie-break draws (no-op in device mode)
             self.graph.replay()
         cur.wait_stream(self.stream)
         self.trainer.step += 1

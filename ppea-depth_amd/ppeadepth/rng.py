@@ -26,17 +26,76 @@ def get_mode() -> str:
     return _MODE
 
 
+# ---- reference-order draws under hipGraph replay ---------------------------------------------------------------
+# A captured step cannot draw on the host.  In "reference" mode the engine therefore records, during one eager
+# warm-up step, every host draw of the step (kind, arguments, a static device tensor) in call order; the captured
+# step reads those static tensors, and before every replay `refill_static()` draws fresh values on the CPU default
+# generator IN THE SAME ORDER (so a seeded run still sees the reference's stream) and copies them in.
+_STATIC = None          # list of [kind, args, device tensor] or None
+_RECORDING = False
+_POS = 0
+
+
+def static_begin_record():
+    global _STATIC, _RECORDING, _POS
+    _STATIC, _RECORDING, _POS = [], True, 0
+
+
+def static_end_record():
+    global _RECORDING, _POS
+    _RECORDING, _POS = False, 0
+
+
+def static_rewind():
+    global _POS
+    _POS = 0
+
+
+def static_clear():
+    global _STATIC, _RECORDING, _POS
+    _STATIC, _RECORDING, _POS = None, False, 0
+
+
+def _draw_cpu(kind, args):
+    if kind == "bernoulli":
+        return torch.empty(args[0], 1, 1, 1, dtype=torch.float32).bernoulli_(args[1])
+    return torch.randn(args[0])
+
+
+def refill_static():
+    if _STATIC is None or _RECORDING:
+        return
+    for kind, args, dev_t in _STATIC:
+        dev_t.copy_(_draw_cpu(kind, args), non_blocking=True)
+    static_rewind()
+
+
+def _host_draw(kind, args, device):
+    """One reference-order draw: eager -> CPU draw copied to the device; recording -> the same, kept as a static
+    buffer; serving (a recorded plan exists) -> the next static buffer, no host work."""
+    global _POS
+    if _STATIC is not None and not _RECORDING:
+        k, a, t = _STATIC[_POS]
+        if (k, a) != (kind, args):
+            raise RuntimeError(f"rng: draw #{_POS} is {kind}{args}, the recorded step had {k}{a}")
+        _POS += 1
+        return t
+    t = _draw_cpu(kind, args).to(device)
+    if _RECORDING:
+        _STATIC.append([kind, args, t])
+    return t
+
+
 def bernoulli_keep(batch: int, keep_prob: float, like: torch.Tensor) -> torch.Tensor:
     """[batch,1,1,1] mask of 0/1 with P(1)=keep_prob, dtype/device of `like`."""
     if _MODE == "reference":
-        m = torch.empty(batch, 1, 1, 1, dtype=torch.float32).bernoulli_(keep_prob)
-        return m.to(device=like.device, dtype=like.dtype)
+        return _host_draw("bernoulli", (int(batch), float(keep_prob)), like.device).to(like.dtype)
     return torch.empty(batch, 1, 1, 1, device=like.device, dtype=like.dtype).bernoulli_(keep_prob)
 
 
 def randn_like_cpu_order(shape, device) -> torch.Tensor:
     if _MODE == "reference":
-        return torch.randn(shape).to(device)
+        return _host_draw("randn", (tuple(int(d) for d in shape),), device)
     return torch.randn(shape, device=device)
 
 
@@ -48,8 +107,11 @@ _AUG_BUFFER = None      # static device tensor [B] the captured step graph reads
 
 
 def set_aug_buffer(t):
+    """Install (or, with None, remove) the static draw buffers of a captured step."""
     global _AUG_BUFFER
     _AUG_BUFFER = t
+    if t is None:
+        static_clear()
 
 
 def refill_aug_buffer():

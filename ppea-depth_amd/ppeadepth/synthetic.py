@@ -70,8 +70,22 @@ def kitti_K(height: int, width: int, scale: int):
     return torch.from_numpy(K), torch.from_numpy(inv_K)
 
 
+def cityscapes_K(height: int, width: int, scale: int):
+    """Normalised intrinsics of the preprocessed Cityscapes frames (cityscapes_preprocessed_dataset.py:37-53:
+    fx = fy ~ 1131 px, principal point at the centre, divided by RAW_WIDTH 1024 / RAW_HEIGHT 384), scaled like
+    mono_dataset.py:173-182."""
+    K = np.array([[1131.0 / 1024, 0, 0.5, 0],
+                  [0, 1131.0 / 384, 0.5, 0],
+                  [0, 0, 1, 0],
+                  [0, 0, 0, 1]], dtype=np.float32)
+    K[0, :] *= width // (2 ** scale)
+    K[1, :] *= height // (2 ** scale)
+    inv_K = np.linalg.pinv(K)
+    return torch.from_numpy(K), torch.from_numpy(inv_K)
+
+
 def make_inputs(batch: int, height: int, width: int, seed: int = 1234,
-                frame_ids=(0, -1, 1), scales=(0, 1, 2, 3), smooth: bool = False):
+                frame_ids=(0, -1, 1), scales=(0, 1, 2, 3), smooth: bool = False, intrinsics: str = "kitti"):
     """The row-P input dict of SURVEY 8(a).  `smooth=True` low-pass filters the
     images so neighbouring frames look alike (keeps losses in a realistic range)."""
     g = torch.Generator(device="cpu")
@@ -91,7 +105,7 @@ def make_inputs(batch: int, height: int, width: int, seed: int = 1234,
             inputs[("color", f, s)] = img.contiguous()
             inputs[("color_aug", f, s)] = img.contiguous().clone()
     for s in scales:
-        K, inv_K = kitti_K(height, width, s)
+        K, inv_K = (kitti_K if intrinsics == "kitti" else cityscapes_K)(height, width, s)
         inputs[("K", s)] = K[None].repeat(batch, 1, 1).contiguous()
         inputs[("inv_K", s)] = inv_K[None].repeat(batch, 1, 1).contiguous()
     return inputs

@@ -591,3 +591,79 @@ def test_decoder_passes_channels_last(device, dtype, shape):
     assert rel_err(y.float().cpu(), ref.detach()) < tol
     assert rel_err(xd.grad.float().cpu(), xr.grad) < max(tol, 2e-5)
     assert rel_err(bd.grad.cpu(), br.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+# ---------------------------------------------------------------------------------------------
+# A3-A6 in isolation: the product MODULES (not only their kernels) against the reference's own module outputs
+# ---------------------------------------------------------------------------------------------
+def _sub(g, prefix):
+    return {n[len(prefix):]: v.clone() for n, v in g.items() if n.startswith(prefix)}
+
+
+def test_replk_modules_vs_reference_golden(device, golden):
+    """`RepLKBlock`, `ConvFFN`, `B_Adapter`, `Adapter` of this build, loaded with the reference modules' state_dicts,
+    against the reference's outputs (tests/golden/replk_blocks.npz: blk:y, ffn:y, badpt:y, adpt:y) and the BN
+    running statistics after one training forward (rka.py:283-289, 315-326)."""
+    from ppeadepth.networks import replknet_adapter as rka
+    g = golden("replk_blocks")
+    x = g["badpt:x"].to(device)
+    C = x.shape[1]
+    ba = rka.B_Adapter(C, adpt_test=4, mlp_ratio=0.25)
+    ba.load_state_dict(_sub(g, "badpt:sd:"))
+    assert rel_err(ba.to(device)(x).cpu(), g["badpt:y"]) < 1e-4
+    ad = rka.Adapter(C, adpt_test=4, mlp_ratio=0.25)
+    ad.load_state_dict(_sub(g, "adpt:sd:"))
+    assert rel_err(ad.to(device)(x).cpu(), g["adpt:y"]) < 1e-4
+    blk = rka.RepLKBlock(C, C, 13, 5, drop_path=0.0, adpt_test=4, ratio=0.25)
+    blk.load_state_dict(_sub(g, "blk:sd:"))
+    blk.to(device).train()
+    assert rel_err(blk(x).cpu(), g["blk:y"]) < 1e-4
+    sd = blk.state_dict()
+    for n, v in _sub(g, "blk:after:").items():
+        assert rel_err(sd[n].cpu(), v) < 1e-4, n
+    ffn = rka.ConvFFN(C, 4 * C, C, drop_path=0.0, adpt_test=4)
+    ffn.load_state_dict(_sub(g, "ffn:sd:"))
+    ffn.to(device).train()
+    assert rel_err(ffn(x).cpu(), g["ffn:y"]) < 1e-4
+
+
+@pytest.mark.parametrize("kind,C,K,H,W", [("blk", 64, 13, 6, 20), ("blk", 128, 31, 24, 40), ("ffn", 64, 0, 12, 40),
+                                           ("ffn", 128, 0, 6, 20)])
+def test_replk_modules_bf16_vs_oracle(device, kind, C, K, H, W):
+    """The bf16 execution of a whole block (pwconv / dwconv_mfma / tapsum / pwgrad / fused BN kernels, adapter on a
+    forked stream) against the fp32 CPU oracle on the same weights: output, input gradient, adapter weight gradients.
+    Tolerance: ~6 chained bf16 roundings of O(1) activations (2^-8 each) -> 3e-2 of the tensor's max."""
+    import types
+    from oracle import ref_model as RM, synth
+    from ppeadepth.networks import replknet_adapter as rka
+    B = 3
+    if kind == "blk":
+        m = rka.RepLKBlock(C, C, K, 5, drop_path=0.0, adpt_test=4, ratio=0.25)
+    else:
+        m = rka.ConvFFN(C, 4 * C, C, drop_path=0.0, adpt_test=4)
+    synth.fill_state_dict(m)
+    sd = {"m." + k: v.clone() for k, v in m.state_dict().items()}
+    names = [n for n, _ in m.named_parameters() if "adapter" in n]
+    for n in names:
+        sd["m." + n].requires_grad_(True)
+    x = torch.randn(B, C, H, W, generator=_g(C + H))
+    go = torch.randn(B, C, H, W, generator=_g(7))
+    opt = types.SimpleNamespace(rep_size="b", g_blk=1.0, g_ffn=1.0, use_checkpoint=False)
+    ref = RM.RefRepDepth(sd, opt)
+    xr = x.clone().requires_grad_(True)
+    yr = ref._replk_block(xr, "m", K, 0.0) if kind == "blk" else ref._conv_ffn(xr, "m", 0.0)
+    yr.backward(go)
+    m.to(device).train()
+    for n, p in m.named_parameters():
+        p.requires_grad = "adapter" in n or ".bn" in n or "_bn" in n        # the Stage-1 freeze rule
+    xd = x.to(device).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(xd.bfloat16())
+    assert y.dtype == torch.bfloat16
+    y.backward(go.to(device).bfloat16())
+    tol = 3e-2
+    assert rel_err(y.float().cpu(), yr.detach()) < tol
+    assert rel_err(xd.grad.cpu(), xr.grad) < tol
+    params = dict(m.named_parameters())
+    for n in names:
+        assert rel_err(params[n].grad.float().cpu(), sd["m." + n].grad) < tol, n

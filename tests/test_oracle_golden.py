@@ -152,18 +152,18 @@ def test_depth_bin_tracker(golden):
 
 
 # ---------------------------------------------------------------------------
-def _run_e2e(g, use_checkpoint=False):
+def _run_e2e(g, use_checkpoint=False, rep_size="b", dc=False, intrinsics="kitti"):
     B, H, W, stride, seed = (int(v) for v in g["meta"])
     opt = types.SimpleNamespace(
-        rep_size="b", g_blk=1.0, g_ffn=1.0, use_checkpoint=use_checkpoint, height=H, width=W,
-        batch_size=B, num_depth_bins=96, min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3)
+        rep_size=rep_size, g_blk=1.0, g_ffn=1.0, use_checkpoint=use_checkpoint, height=H, width=W,
+        batch_size=B, num_depth_bins=96, min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, dc=dc)
     from oracle import model_spec
     sd = {k: synth.synth_tensor(k, torch.empty(shape, dtype=dt))
-          for k, (shape, dt) in model_spec.state_spec("b").items()}
+          for k, (shape, dt) in model_spec.state_spec(rep_size, dc=dc).items()}
     sd = RM.leaf_state_dict(sd, opt)
     model = RM.RefRepDepth(sd, opt)
     tr = RM.RefTrainer(model, opt)
-    inputs = synth.make_inputs(B, H, W)
+    inputs = synth.make_inputs(B, H, W, intrinsics=intrinsics)
     torch.manual_seed(seed)
     random.seed(seed)
     outputs, losses = tr.process_batch(inputs)
@@ -220,6 +220,23 @@ def test_e2e_small_checkpoint_semantics(golden):
 def test_e2e_full(golden):
     g = golden("e2e_full")
     _check_e2e(g, *_run_e2e(g))
+
+
+def test_e2e_replknet31l(golden):
+    """BASELINE config 4's model (RepLKNet-31L, 1.5x channels) at 64x96."""
+    g = golden("e2e_l")
+    _check_e2e(g, *_run_e2e(g, rep_size="l"))
+
+
+@pytest.mark.slow
+def test_e2e_stage2_decoder_adapter(golden):
+    """BASELINE config 5: `--dc` after dc_ft_init (decoder adapter + deconv trainable, decoder frozen) at the
+    reference-faithful Cityscapes size 192x512 (trainer.py:90-93)."""
+    g = golden("e2e_dc")
+    outputs, losses, sd, tr, inputs, stride = _run_e2e(g, dc=True, intrinsics="cityscapes")
+    _check_e2e(g, outputs, losses, sd, tr, inputs, stride)
+    assert sd["depth.upconvs_0.0.conv.conv.weight"].grad is None          # frozen by dc_ft_init
+    assert sd["depth.deconv_adpt.weight"].grad is not None
 
 
 @pytest.mark.parametrize("size", ["b", "l"])
