@@ -234,16 +234,21 @@ def main():
         deadline = float(os.environ.get("PPEA_GRAPH_DEADLINE_S", "240"))
 
         def on_timeout():
-            print(f"[bench] rank {rank}: captured step did not finish within {deadline:.0f} s; reporting the eager run",
+            # A hang is a FAILURE: the eager measurement taken before the attempt is printed for diagnosis, marked
+            # `"hang": true`, and the process exits non-zero so the run cannot be mistaken for a successful one.
+            print(f"[bench] rank {rank}: captured multi-rank step did not finish within {deadline:.0f} s -- HANG; "
+                  f"printing the eager measurement taken before the attempt and exiting with status 3",
                   file=sys.stderr, flush=True)
             if rank == 0:
-                emit(fallback[0], fallback[1], True, "eager (captured multi-rank step timed out)")
-            os._exit(0)
+                emit(fallback[0], fallback[1], True, "eager (captured multi-rank step HUNG; see stderr)", hang=True)
+            os._exit(3)
         watchdog = threading.Timer(deadline, on_timeout)
         watchdog.daemon = True
 
-    def emit(dt, loss_val, eager, launch):
+    def emit(dt, loss_val, eager, launch, hang=False):
         line = make_line(dt, loss_val, launch)
+        if hang:
+            line["hang"] = True
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline()

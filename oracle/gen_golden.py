@@ -285,6 +285,9 @@ def gen_e2e(name, B, H, W, extra=(), stride=1, seed=1, grad_keys=None, intrinsic
         arrays["grad_sum:" + k] = g.double().sum().float()
         arrays["grad_abs:" + k] = g.double().abs().sum().float()
         arrays["grad_head:" + k] = g.reshape(-1)[:32].clone()
+        # up to 4096 evenly strided elements: L2 / cosine comparisons for reduced-precision runs
+        flat = g.reshape(-1)
+        arrays["grad_sample:" + k] = flat[::max(1, flat.numel() // 4096)][:4096].clone()
     sd = model.state_dict()
     for k in ("encoder.replk.stem.0.bn.running_mean", "encoder.replk.stem.0.bn.running_var",
               "mono_encoder.stages.3.blocks.3.pw2.bn.running_var",

@@ -137,6 +137,29 @@ def _global_stats(bn, z):
     return mean, invstd, float(cnt * world), (group,)
 
 
+def _global_stats_pair(bn1, z1, bn2, z2):
+    """Two BNs over tensors that exist at the same time (the k x k and 5 x 5 branches of a re-parameterised large-kernel
+    conv, rka.py:232-239): their SyncBN statistics travel in ONE packed all-gather instead of two."""
+    from . import ops
+    if not (bn1.sync and bn2.sync and _collectives_on()) or getattr(bn1, "group", None) is not getattr(bn2, "group", None):
+        return _global_stats(bn1, z1), _global_stats(bn2, z2)
+    group = getattr(bn1, "group", None)
+    world = dist.get_world_size(group)
+    p1, p2 = ops.bn_local_stats_packed(z1), ops.bn_local_stats_packed(z2)
+    n1 = p1.numel()
+    packed = torch.cat([p1, p2])
+    gathered = torch.empty(world, packed.numel(), device=z1.device, dtype=packed.dtype)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(gathered, packed, group=group)
+    else:
+        dist.all_gather(list(gathered.unbind(0)), packed, group=group)
+    out = []
+    for bn, z, g in ((bn1, z1, gathered[:, :n1]), (bn2, z2, gathered[:, n1:])):
+        mean, invstd = ops.bn_sync_combine(g.contiguous(), bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        out.append((mean, invstd, float(z.numel() // z.shape[1] * world), (group,)))
+    return out[0], out[1]
+
+
 def assign_groups(model):
     """One process group per concurrently running branch: ProcessGroupNCCL runs a group's collectives in order
     on one internal stream, so the teacher's and the student's SyncBN exchanges must not share a group or the
@@ -163,9 +186,12 @@ def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None,
     bns = [(z1, bn1)] + ([(z2, bn2)] if z2 is not None else [])
     stats = []
     count, group = None, None
+    pre = None
+    if z2 is not None and bn1.training and bn2.training:
+        pre = list(_global_stats_pair(bn1, z1, bn2, z2))
     for z, bn in bns:
         if bn.training:
-            mean, invstd, count, group = _global_stats(bn, z)
+            mean, invstd, count, group = pre.pop(0) if pre is not None else _global_stats(bn, z)
             if _ACTIVE_DEFERRED is None:
                 bn.num_batches_tracked += 1
             else:

@@ -8,9 +8,9 @@ all-reduce of the trainable gradients (80.3 M fp32 = 321 MB at 31B; 1 306 tensor
 MI355X design: xGMI is point-to-point (7 links x ~153 GB/s per GPU), so few, large collectives win.
 All trainable gradients live in ONE flat fp32 buffer (`FlatGrads`): `p.grad` of every trainable
 parameter is a view into it, autograd accumulates straight into the buffer, zeroing is one
-memset, and the exchange is `n_chunks` all-reduces of ~40-80 MB each issued on a side stream as
-soon as the backward has produced the chunk (parameters are laid out in reverse registration
-order, i.e. roughly in the order backward finishes them).
+memset, and the exchange is `n_chunks` all-reduces of ~40-80 MB each, issued on a side stream from
+autograd hooks as soon as backward has produced the last gradient of a chunk (`FlatGrads.install_hooks`;
+parameters are laid out in reverse registration order, i.e. roughly in the order backward finishes them).
 """
 import os
 
@@ -85,6 +85,7 @@ class FlatGrads:
                 self.bounds.append(off)
         self.bounds.append(self.numel)
         self.comm_stream = torch.cuda.Stream(device) if device.type == "cuda" else None
+        self.hooked = False
 
     def zero(self):
         self.flat.zero_()
@@ -101,6 +102,91 @@ class FlatGrads:
                 src.append(p.grad)
         for dst, src in groups.values():
             torch._foreach_copy_(dst, src)
+        for t, v in zip(self.targets, self.views):
+            t.grad = v
+
+    # ---- gradient exchange overlapped with backward -------------------------------------------------------------
+    # `sources[i]` is the model parameter whose gradient lands in `views[i]` (the parameter itself, or the bf16 working
+    # copy of an fp32 master).  A post-accumulate hook on every source counts the chunk's outstanding gradients down
+    # as autograd produces them; the hook that completes a chunk enqueues, on the communication stream, (1) a wait
+    # for every stream that produced one of the chunk's gradients, (2) ONE multi-tensor copy per dtype of the chunk's
+    # gradients into the flat buffer, (3) the chunk's mean all-reduce -- while autograd keeps going on the compute
+    # streams.  Parameters are laid out in reverse registration order, so chunk 0 (the heads and decoders) goes out
+    # first and the last chunk (encoder stems) right at the end of backward.  Under graph capture the same enqueue
+    # order becomes the graph's dependency structure.  Reference: DDP's bucketed all-reduce (trainer.py:220-222, 350).
+    def install_hooks(self, sources):
+        import bisect
+        self.sources = list(sources)
+        assert len(self.sources) == len(self.views)
+        self._chunk_of = [bisect.bisect_right(self.bounds, off) - 1 for off in self.offsets]
+        n = len(self.bounds) - 1
+        self._members = [[i for i, c in enumerate(self._chunk_of) if c == k] for k in range(n)]
+        self._left, self._streams, self._fired = [0] * n, [set() for _ in range(n)], set()
+        self._active = False
+        for i, p in enumerate(self.sources):
+            p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
+        self.hooked = True
+
+    def begin_backward(self):
+        """Call right before loss.backward(): arms the hooks for one backward pass."""
+        self._left = [len(m) for m in self._members]
+        self._streams = [set() for _ in self._members]
+        self._fired = set()
+        self._launched = [False] * len(self._members)
+        self._active = True
+
+    def _on_grad(self, i):
+        if not self._active or i in self._fired:
+            return
+        self._fired.add(i)
+        c = self._chunk_of[i]
+        if self.comm_stream is not None:
+            self._streams[c].add(torch.cuda.current_stream())
+        self._left[c] -= 1
+        if self._left[c] == 0:
+            self._launch_chunk(c)
+
+    @torch.no_grad()
+    def _launch_chunk(self, c):
+        self._launched[c] = True
+        a, b = self.bounds[c], self.bounds[c + 1]
+        w = world_size()
+
+        def body():
+            groups = {}
+            for i in self._members[c]:
+                g = self.sources[i].grad
+                if i not in self._fired or g is None:
+                    self.views[i].zero_()                  # no gradient this step (unused parameter)
+                elif g.data_ptr() != self.views[i].data_ptr():
+                    dst, src = groups.setdefault(g.dtype, ([], []))
+                    dst.append(self.views[i])
+                    src.append(g)
+            for dst, src in groups.values():
+                torch._foreach_copy_(dst, src)
+            chunk = self.flat[a:b]
+            if collectives_on():
+                dist.all_reduce(chunk)
+                chunk.mul_(1.0 / w)
+        if self.comm_stream is None:
+            body()
+            return
+        for st in self._streams[c] or {torch.cuda.current_stream()}:
+            self.comm_stream.wait_stream(st)
+        with torch.cuda.stream(self.comm_stream):
+            body()
+
+    def finish(self):
+        """After backward: flush chunks with parameters that received no gradient, join the communication stream,
+        hand the reduced views to the optimizer's tensors."""
+        for c in range(len(self._members)):
+            if not self._launched[c]:
+                if self.comm_stream is not None:
+                    self._streams[c].add(torch.cuda.current_stream())
+                self._launch_chunk(c)
+        self._active = False
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
         for t, v in zip(self.targets, self.views):
             t.grad = v
 
@@ -125,6 +211,7 @@ class FlatGrads:
 
 
 FLAT_ADAM = True     # one-launch Adam over a flat parameter buffer (GPU, fused path)
+OVERLAP_ALLREDUCE = True   # several ranks: chunked gradient all-reduce launched from autograd hooks during backward
 
 
 class TrainEngine:
@@ -158,6 +245,8 @@ class TrainEngine:
             self._hi = [self.masters[id(p)] for p in self._lo]
         self.flat = FlatGrads(self.opt_params, n_chunks, align=128 if self.flat_adam else 1) \
             if (collectives_on() or self.flat_adam) else None
+        if self.flat is not None and collectives_on() and OVERLAP_ALLREDUCE:
+            self.flat.install_hooks(self.params)       # gradient exchange overlapped with backward
         if self.flat is None and self._lo:
             self._hi_grads = [torch.zeros_like(m) for m in self._hi]
             for m, g in zip(self._hi, self._hi_grads):
@@ -283,8 +372,10 @@ class TrainEngine:
         rng.refill_aug_buffer()
         rng.static_rewind()
         torch.cuda.synchronize()
+        # the dict the captured step saw: process_batch adds ("relative_pose", f) entries to it (repdepth.py:507)
+        self.static_step_inputs = dict(self.static_inputs)
         with torch.cuda.graph(self.graph, stream=self.stream):
-            outputs, losses = self._step_body(dict(self.static_inputs))
+            outputs, losses = self._step_body(self.static_step_inputs)
         self.static_out = (outputs, losses)
         if snap is not None:
             self.restore(snap)
@@ -352,12 +443,16 @@ class TrainEngine:
         outputs, losses = self.trainer.process_batch(inputs, is_train=True)
         for p in self.params:
             p.grad = None              # autograd then hands each gradient over without an accumulate kernel
+        if self.flat is not None and self.flat.hooked:
+            self.flat.begin_backward()
         losses["loss"].backward()
         self._optimizer_phase()
         return outputs, losses
 
     def _optimizer_phase(self):
-        if self.flat is not None:      # pack -> (several ranks: few large all-reduces) -> Adam on the flat buffer
+        if self.flat is not None and self.flat.hooked:
+            self.flat.finish()         # chunks were packed and all-reduced from the hooks, during backward
+        elif self.flat is not None:    # pack -> (several ranks: few large all-reduces) -> Adam on the flat buffer
             self.flat.gather(self.params)
             self.flat.all_reduce_mean()
         elif self._lo:                 # bf16 working weights: bf16 grads -> fp32 master grads

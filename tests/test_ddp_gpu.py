@@ -103,3 +103,62 @@ def test_two_ranks_match_global_batch(device):
     # both ranks hold identical running statistics and identical updated weights after the step
     assert torch.equal(res[0][3], res[1][3])
     assert all(l == l for l in (res[0][4], res[1][4]))
+
+
+# ---------------------------------------------------------------------------------------------
+# real RCCL, two devices: skipped on a one-GPU box (the development box has one); runs wherever >= 2 GPUs are visible
+# ---------------------------------------------------------------------------------------------
+def _nccl_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "ppea-depth_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from oracle import synth
+    from ppeadepth import batchnorm, dist as pdist, networks, options, rng
+    from ppeadepth.trainer import Trainer
+    pdist.init_distributed("nccl")
+    dev = torch.device("cuda", rank)
+    opt = options.default_options(height=H, width=W, batch_size=1, use_checkpoint=True)
+    model = networks.RepDepth(opt)
+    synth.fill_state_dict(model)
+    model.to(dev).train()
+    pdist.broadcast_module(model)
+    batchnorm.assign_groups(model)
+    tr = Trainer(opt, model, dev, amp_dtype=torch.bfloat16)
+    eng = pdist.TrainEngine(tr, lr=1e-4, bf16_params=True)
+    assert eng.flat.hooked                      # gradient exchange overlapped with backward
+    rng.set_mode("device")
+    full = synth.make_inputs(B_GLOBAL, H, W, smooth=True)
+    inputs = {k: v[rank:rank + 1].to(dev).contiguous() for k, v in full.items()}
+    random.seed(rank)
+    l_eager = float(eng.step(dict(inputs))[1]["loss"])
+    eng.capture(inputs, warmup=1)               # the captured step holds the RCCL calls
+    l_graph = [float(eng.step(inputs)[1]["loss"]) for _ in range(2)]
+    torch.cuda.synchronize()
+    sd = model.state_dict()
+    probe = torch.cat([sd["encoder.replk.stem.0.bn.running_var"].float().cpu(),
+                       eng.P[:4096].float().cpu()])
+    q.put((rank, probe, l_eager, l_graph))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
+def test_two_ranks_rccl_eager_and_captured(device):
+    """Two RCCL ranks, bf16 step, hook-driven gradient all-reduce, SyncBN exchanges on per-branch communicators,
+    eager and captured: identical running statistics and master weights on both ranks, finite losses."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert torch.equal(res[0][1], res[1][1])
+    for r in res:
+        assert all(v == v for v in [r[2]] + r[3])

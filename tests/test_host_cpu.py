@@ -196,6 +196,22 @@ def _dp_worker(rank, world, port, q):
     got = torch.cat([p.grad.reshape(-1) for p in params])
     ok_grad = torch.allclose(got, want, atol=1e-6)
     ok_view = all(p.grad.data_ptr() >= flat.flat.data_ptr() for p in params) and model[3].weight.grad is None
+    # the same exchange launched from autograd hooks during backward (one copy + all-reduce per finished chunk), with
+    # a trainable parameter that receives no gradient this step
+    unused = torch.nn.Parameter(torch.ones(7))
+    params2 = params + [unused]
+    flat2 = pdist.FlatGrads(params2, n_chunks=3)
+    flat2.flat.fill_(123.0)                              # stale contents must not survive
+    flat2.install_hooks(params2)
+    for p in params2:
+        p.grad = None
+    flat2.begin_backward()
+    model(x).pow(2).sum().backward()
+    launched_in_backward = sum(flat2._launched)
+    flat2.finish()
+    got2 = torch.cat([p.grad.reshape(-1) for p in params])
+    ok_grad = ok_grad and torch.allclose(got2, want, atol=1e-6) and bool((unused.grad == 0).all()) \
+        and unused.grad.data_ptr() >= flat2.flat.data_ptr() and launched_in_backward >= 1
     # depth-bin tracker: min over ranks of min_depth, max over ranks of max_depth (torchmetrics dist_reduce_fx)
     tr = DepthBins(0.1)
     tr.min_depth = torch.tensor(0.2 + rank)

@@ -627,21 +627,37 @@ def test_replk_modules_vs_reference_golden(device, golden):
     assert rel_err(ffn(x).cpu(), g["ffn:y"]) < 1e-4
 
 
+def _l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
 @pytest.mark.parametrize("kind,C,K,H,W", [("blk", 64, 13, 6, 20), ("blk", 128, 31, 24, 40), ("ffn", 64, 0, 12, 40),
                                            ("ffn", 128, 0, 6, 20)])
 def test_replk_modules_bf16_vs_oracle(device, kind, C, K, H, W):
     """The bf16 execution of a whole block (pwconv / dwconv_mfma / tapsum / pwgrad / fused BN kernels, adapter on a
     forked stream) against the fp32 CPU oracle on the same weights: output, input gradient, adapter weight gradients.
-    Tolerance: ~6 chained bf16 roundings of O(1) activations (2^-8 each) -> 3e-2 of the tensor's max."""
+
+    Tolerances: the forward output sees ~6 chained bf16 roundings of O(1) activations -> 3e-2 of the tensor's max
+    (measured 7e-3).  `ConvFFN` is smooth (GELU), so its gradients hold the same bound.  `RepLKBlock` has two ReLU
+    gates: a pre-activation within 2^-9 of zero flips its gate under ANY bf16 execution and moves that gradient entry
+    by 100 % (one such flip even separates two fp32 implementations: 0.2 in max-norm, 2e-2 in L2 at C=64, 6x20 --
+    tools/debug_misc.py), so its gradients are compared in L2 and bounded by 1.5x the L2 error of torch's own bf16
+    autocast of the same module (+ floor)."""
     import types
     from oracle import ref_model as RM, synth
+    from ppeadepth import ops
     from ppeadepth.networks import replknet_adapter as rka
     B = 3
-    if kind == "blk":
-        m = rka.RepLKBlock(C, C, K, 5, drop_path=0.0, adpt_test=4, ratio=0.25)
-    else:
-        m = rka.ConvFFN(C, 4 * C, C, drop_path=0.0, adpt_test=4)
-    synth.fill_state_dict(m)
+
+    def make():
+        if kind == "blk":
+            m = rka.RepLKBlock(C, C, K, 5, drop_path=0.0, adpt_test=4, ratio=0.25)
+        else:
+            m = rka.ConvFFN(C, 4 * C, C, drop_path=0.0, adpt_test=4)
+        synth.fill_state_dict(m)
+        return m
+    m = make()
     sd = {"m." + k: v.clone() for k, v in m.state_dict().items()}
     names = [n for n, _ in m.named_parameters() if "adapter" in n]
     for n in names:
@@ -653,17 +669,35 @@ def test_replk_modules_bf16_vs_oracle(device, kind, C, K, H, W):
     xr = x.clone().requires_grad_(True)
     yr = ref._replk_block(xr, "m", K, 0.0) if kind == "blk" else ref._conv_ffn(xr, "m", 0.0)
     yr.backward(go)
-    m.to(device).train()
-    for n, p in m.named_parameters():
-        p.requires_grad = "adapter" in n or ".bn" in n or "_bn" in n        # the Stage-1 freeze rule
-    xd = x.to(device).requires_grad_(True)
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        y = m(xd.bfloat16())
+
+    def run():
+        mod = make().to(device).train()
+        for n, p in mod.named_parameters():
+            p.requires_grad = "adapter" in n or ".bn" in n or "_bn" in n        # the Stage-1 freeze rule
+        xd = x.to(device).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = mod(xd.bfloat16())
+        y.backward(go.to(device).bfloat16())
+        params = dict(mod.named_parameters())
+        return y, xd.grad, {n: params[n].grad for n in names}
+
+    y, dx, dw = run()
     assert y.dtype == torch.bfloat16
-    y.backward(go.to(device).bfloat16())
-    tol = 3e-2
-    assert rel_err(y.float().cpu(), yr.detach()) < tol
-    assert rel_err(xd.grad.cpu(), xr.grad) < tol
-    params = dict(m.named_parameters())
+    assert rel_err(y.float().cpu(), yr.detach()) < 3e-2
+    if kind == "ffn":
+        assert rel_err(dx.cpu(), xr.grad) < 3e-2
+        for n in names:
+            assert rel_err(dw[n].float().cpu(), sd["m." + n].grad) < 3e-2, n
+        return
+    saved = (rka.FUSE_BN, rka.PW_MFMA, rka.ADAPTER_MFMA, ops._MFMA_K)
+    try:
+        rka.FUSE_BN = rka.PW_MFMA = rka.ADAPTER_MFMA = False
+        ops._MFMA_K = ()
+        _, dx_t, dw_t = run()
+    finally:
+        rka.FUSE_BN, rka.PW_MFMA, rka.ADAPTER_MFMA, ops._MFMA_K = saved
+    e, et = _l2(dx.cpu(), xr.grad), _l2(dx_t.cpu(), xr.grad)
+    assert e < 1.5 * et + 1e-2 and e < 0.3, ("dx", e, et)
     for n in names:
-        assert rel_err(params[n].grad.float().cpu(), sd["m." + n].grad) < tol, n
+        e, et = _l2(dw[n].float().cpu(), sd["m." + n].grad), _l2(dw_t[n].float().cpu(), sd["m." + n].grad)
+        assert e < 1.5 * et + 1e-2 and e < 0.3, (n, e, et)
