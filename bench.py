@@ -285,6 +285,13 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
 
+    if rank == 0 and engine.flat is not None and engine.flat.hooked:
+        plan = engine.flat.last_plan
+        total = sum(p[2] for p in plan)
+        early = sum(p[2] for p in plan if p[3])
+        print(f"[bench] gradient exchange: {len(plan)} ranges, {early / max(total, 1):.0%} of {total * 4 / 1e6:.0f} MB "
+              f"launched from autograd hooks during backward: "
+              + ", ".join(f"{p[2] * 4 / 1e6:.0f}MB{'*' if p[3] else ''}" for p in plan), file=sys.stderr, flush=True)
     if rank == 0:
         emit(dt, loss_val, args.eager, "eager" if args.eager else "whole step captured in one hipGraph")
     if dist.is_initialized():

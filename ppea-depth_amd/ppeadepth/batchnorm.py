@@ -137,11 +137,15 @@ def _global_stats(bn, z):
     return mean, invstd, float(cnt * world), (group,)
 
 
+PACK_PAIR = __import__("os").environ.get("PPEA_BN_PAIR", "1") == "1"
+
+
 def _global_stats_pair(bn1, z1, bn2, z2):
     """Two BNs over tensors that exist at the same time (the k x k and 5 x 5 branches of a re-parameterised large-kernel
     conv, rka.py:232-239): their SyncBN statistics travel in ONE packed all-gather instead of two."""
     from . import ops
-    if not (bn1.sync and bn2.sync and _collectives_on()) or getattr(bn1, "group", None) is not getattr(bn2, "group", None):
+    if not (PACK_PAIR and bn1.sync and bn2.sync and _collectives_on()) \
+            or getattr(bn1, "group", None) is not getattr(bn2, "group", None):
         return _global_stats(bn1, z1), _global_stats(bn2, z2)
     group = getattr(bn1, "group", None)
     world = dist.get_world_size(group)

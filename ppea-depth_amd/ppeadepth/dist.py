@@ -52,8 +52,18 @@ def broadcast_module(module, src=0):
     """Replicate parameters and buffers from `src` (what DDP does at construction)."""
     if world_size() == 1:
         return
+    # one flat broadcast per dtype (2 888 tensors at 31B: per-tensor broadcasts are latency-bound)
+    by_dtype = {}
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src)
+        by_dtype.setdefault(t.dtype, []).append(t.data)
+    with torch.no_grad():
+        for ts in by_dtype.values():
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.broadcast(flat, src)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
 
 
 class FlatGrads:
@@ -107,86 +117,88 @@ class FlatGrads:
 
     # ---- gradient exchange overlapped with backward -------------------------------------------------------------
     # `sources[i]` is the model parameter whose gradient lands in `views[i]` (the parameter itself, or the bf16 working
-    # copy of an fp32 master).  A post-accumulate hook on every source counts the chunk's outstanding gradients down
-    # as autograd produces them; the hook that completes a chunk enqueues, on the communication stream, (1) a wait
-    # for every stream that produced one of the chunk's gradients, (2) ONE multi-tensor copy per dtype of the chunk's
-    # gradients into the flat buffer, (3) the chunk's mean all-reduce -- while autograd keeps going on the compute
-    # streams.  Parameters are laid out in reverse registration order, so chunk 0 (the heads and decoders) goes out
-    # first and the last chunk (encoder stems) right at the end of backward.  Under graph capture the same enqueue
-    # order becomes the graph's dependency structure.  Reference: DDP's bucketed all-reduce (trainer.py:220-222, 350).
-    def install_hooks(self, sources):
-        import bisect
+    # copy of an fp32 master).  The buffer is cut into RANGES of tensors whose gradients autograd produces on the same
+    # stream (`groups`: one id per target; TrainEngine derives them from the branch structure of the step -- teacher
+    # encoder / decoder on the teacher's stream, student adapters on the adapter stream, the rest on the step stream).
+    # A post-accumulate hook on every source counts its range down; the hook that completes a range enqueues, IN LINE
+    # on the stream that produced the range, ONE multi-tensor copy per dtype into the flat buffer and the range's mean
+    # all-reduce -- while the other branches of backward keep the GPU busy.  No extra stream and no new fork/join edges:
+    # measured on MI355X, a separate communication stream that joins several branches mid-backward costs the captured
+    # step 9 ms (the hipGraph executor stops overlapping the branches), in-line launches do not.  A range whose
+    # gradients turn out to come from more than one stream is not launched from a hook but after backward, where
+    # autograd has joined all streams (so correctness never rests on the grouping rule).
+    # Reference: DDP's bucketed all-reduce overlapped with backward (trainer.py:220-222, 350).
+    def install_hooks(self, sources, groups=None):
         self.sources = list(sources)
         assert len(self.sources) == len(self.views)
-        self._chunk_of = [bisect.bisect_right(self.bounds, off) - 1 for off in self.offsets]
-        n = len(self.bounds) - 1
-        self._members = [[i for i, c in enumerate(self._chunk_of) if c == k] for k in range(n)]
-        self._left, self._streams, self._fired = [0] * n, [set() for _ in range(n)], set()
+        if groups is None:                     # ranges = the size-balanced chunks
+            import bisect
+            groups = [bisect.bisect_right(self.bounds, off) - 1 for off in self.offsets]
+        ranges, start = [], 0                  # maximal runs of equal group id -> [first tensor, last tensor + 1)
+        for i in range(1, len(groups) + 1):
+            if i == len(groups) or groups[i] != groups[start]:
+                ranges.append((start, i))
+                start = i
+        self._ranges = ranges
+        self._range_of = [k for k, (a, b) in enumerate(ranges) for _ in range(a, b)]
         self._active = False
+        self._launched = [True] * len(ranges)
         for i, p in enumerate(self.sources):
             p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i))
         self.hooked = True
 
     def begin_backward(self):
         """Call right before loss.backward(): arms the hooks for one backward pass."""
-        self._left = [len(m) for m in self._members]
-        self._streams = [set() for _ in self._members]
+        self._left = [b - a for a, b in self._ranges]
+        self._streams = [set() for _ in self._ranges]
         self._fired = set()
-        self._launched = [False] * len(self._members)
+        self._launched = [False] * len(self._ranges)
         self._active = True
 
     def _on_grad(self, i):
         if not self._active or i in self._fired:
             return
         self._fired.add(i)
-        c = self._chunk_of[i]
-        if self.comm_stream is not None:
-            self._streams[c].add(torch.cuda.current_stream())
-        self._left[c] -= 1
-        if self._left[c] == 0:
-            self._launch_chunk(c)
+        k = self._range_of[i]
+        cuda = self.flat.is_cuda
+        if cuda:
+            self._streams[k].add(torch.cuda.current_stream())
+        self._left[k] -= 1
+        if self._left[k] == 0 and (not cuda or len(self._streams[k]) == 1):
+            self._launch_range(k)              # in line, on the stream that produced every gradient of the range
 
     @torch.no_grad()
-    def _launch_chunk(self, c):
-        self._launched[c] = True
-        a, b = self.bounds[c], self.bounds[c + 1]
-        w = world_size()
-
-        def body():
-            groups = {}
-            for i in self._members[c]:
-                g = self.sources[i].grad
-                if i not in self._fired or g is None:
-                    self.views[i].zero_()                  # no gradient this step (unused parameter)
-                elif g.data_ptr() != self.views[i].data_ptr():
-                    dst, src = groups.setdefault(g.dtype, ([], []))
-                    dst.append(self.views[i])
-                    src.append(g)
-            for dst, src in groups.values():
-                torch._foreach_copy_(dst, src)
-            chunk = self.flat[a:b]
-            if collectives_on():
-                dist.all_reduce(chunk)
-                chunk.mul_(1.0 / w)
-        if self.comm_stream is None:
-            body()
-            return
-        for st in self._streams[c] or {torch.cuda.current_stream()}:
-            self.comm_stream.wait_stream(st)
-        with torch.cuda.stream(self.comm_stream):
-            body()
+    def _launch_range(self, k):
+        self._launched[k] = True
+        a, b = self._ranges[k]
+        groups = {}
+        for i in range(a, b):
+            g = self.sources[i].grad
+            if i not in self._fired or g is None:
+                self.views[i].zero_()                      # no gradient this step (unused parameter)
+            elif g.data_ptr() != self.views[i].data_ptr():
+                dst, src = groups.setdefault(g.dtype, ([], []))
+                dst.append(self.views[i])
+                src.append(g)
+        for dst, src in groups.values():
+            torch._foreach_copy_(dst, src)
+        lo = self.offsets[a]
+        hi = self.offsets[b] if b < len(self.offsets) else self.numel
+        if collectives_on():
+            chunk = self.flat[lo:hi]
+            dist.all_reduce(chunk)
+            chunk.mul_(1.0 / world_size())
 
     def finish(self):
-        """After backward: flush chunks with parameters that received no gradient, join the communication stream,
-        hand the reduced views to the optimizer's tensors."""
-        for c in range(len(self._members)):
-            if not self._launched[c]:
-                if self.comm_stream is not None:
-                    self._streams[c].add(torch.cuda.current_stream())
-                self._launch_chunk(c)
+        """After backward (autograd has joined every stream it used with the current one): launch what the hooks did
+        not -- ranges with unused parameters or mixed producer streams -- and hand the views to the optimizer."""
+        self.last_plan = []                    # (first tensor, tensors, elements, launched from a hook?) per range
+        for k, (a, b) in enumerate(self._ranges):
+            hi = self.offsets[b] if b < len(self.offsets) else self.numel
+            self.last_plan.append((a, b - a, hi - self.offsets[a], bool(self._launched[k])))
+            if not self._launched[k]:
+                self._launch_range(k)
         self._active = False
-        if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
         for t, v in zip(self.targets, self.views):
             t.grad = v
 
@@ -211,7 +223,22 @@ class FlatGrads:
 
 
 FLAT_ADAM = True     # one-launch Adam over a flat parameter buffer (GPU, fused path)
-OVERLAP_ALLREDUCE = True   # several ranks: chunked gradient all-reduce launched from autograd hooks during backward
+# several ranks: chunked gradient all-reduce launched from autograd hooks during backward (PPEA_OVERLAP=0: after it)
+OVERLAP_ALLREDUCE = os.environ.get("PPEA_OVERLAP", "1") == "1"
+
+
+# Branches of the step's backward pass, in the order they finish (networks/repdepth.py forks the teacher onto a side
+# stream and replknet_adapter.py the student's adapters onto another): gradients of one branch are produced on one stream.
+_BRANCH_ORDER = ("depth", "mono_depth", "encoder_adapters", "encoder", "mono_encoder", "pose")
+
+
+def _branch_of(name):
+    top = name.split(".")[0]
+    if top in ("mono_depth", "mono_encoder", "depth"):
+        return top
+    if top == "encoder":
+        return "encoder_adapters" if (".adapter." in name or ".mlp_adapter." in name) else "encoder"
+    return "pose"            # pose_encoder, pose (and anything else: launched after backward if streams mix)
 
 
 class TrainEngine:
@@ -226,6 +253,11 @@ class TrainEngine:
         self.params = [p for p in model.parameters() if p.requires_grad]
         # reverse registration order ~ the order in which backward finishes the gradients
         self.params = list(reversed(self.params))
+        if collectives_on() and OVERLAP_ALLREDUCE:
+            # tensors of one backward branch sit together (stable sort: reverse registration order inside a branch)
+            names = {id(p): n for n, p in model.named_parameters()}
+            rank_of = {b: i for i, b in enumerate(_BRANCH_ORDER)}
+            self.params.sort(key=lambda p: rank_of[_branch_of(names[id(p)])])
         lr = trainer.opt.learning_rate if lr is None else lr
         on_gpu = self.params[0].is_cuda
         if fused_adam is None:
@@ -246,7 +278,9 @@ class TrainEngine:
         self.flat = FlatGrads(self.opt_params, n_chunks, align=128 if self.flat_adam else 1) \
             if (collectives_on() or self.flat_adam) else None
         if self.flat is not None and collectives_on() and OVERLAP_ALLREDUCE:
-            self.flat.install_hooks(self.params)       # gradient exchange overlapped with backward
+            # gradient exchange overlapped with backward, one range per (branch of the step, dtype class)
+            names = {id(p): n for n, p in model.named_parameters()}
+            self.flat.install_hooks(self.params, [_branch_of(names[id(p)]) for p in self.params])
         if self.flat is None and self._lo:
             self._hi_grads = [torch.zeros_like(m) for m in self._hi]
             for m, g in zip(self._hi, self._hi_grads):

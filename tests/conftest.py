@@ -13,6 +13,11 @@ for p in (ROOT, PKG):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# A GPU box exposes all host cores (128+) but grants a 16-core share: torch's default thread count then oversubscribes
+# every CPU-side phase of the suite (model construction, synthetic weights, the oracle).
+torch.set_num_threads(min(torch.get_num_threads(), 16))
+os.environ.setdefault("OMP_NUM_THREADS", "16")        # inherited by spawned worker processes
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

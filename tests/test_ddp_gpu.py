@@ -50,17 +50,23 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, os.path.join(root, "ppea-depth_amd"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0")
+    import time
+    t0 = time.time()
     from oracle import synth
     from ppeadepth import dist as pdist
     pdist.init_distributed("gloo")
     _patch_rng()
     opt, model, tr, dev = _build(1)
+    t1 = time.time()
     pdist.broadcast_module(model)
+    t2 = time.time()
     eng = pdist.TrainEngine(tr, lr=1e-4)
     full = synth.make_inputs(B_GLOBAL, H, W, smooth=True)
     inputs = {k: v[rank:rank + 1].to(dev).contiguous() for k, v in full.items()}
     outputs, losses = eng.step(dict(inputs))
     torch.cuda.synchronize()
+    print(f"[ddp worker {rank}] import+build {t1 - t0:.1f} s, broadcast {t2 - t1:.1f} s, step {time.time() - t2:.1f} s",
+          flush=True)
     sd = model.state_dict()
     probe = torch.cat([sd["encoder.replk.stem.0.bn.running_var"].float().cpu(),
                        sd["mono_encoder.stages.2.blocks.7.pw2.bn.running_mean"].float().cpu(),

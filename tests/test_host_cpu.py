@@ -202,12 +202,13 @@ def _dp_worker(rank, world, port, q):
     params2 = params + [unused]
     flat2 = pdist.FlatGrads(params2, n_chunks=3)
     flat2.flat.fill_(123.0)                              # stale contents must not survive
-    flat2.install_hooks(params2)
+    flat2.install_hooks(params2, groups=["a", "a", "b", "b", "c"][:len(params2) - 1] + ["c"])
     for p in params2:
         p.grad = None
     flat2.begin_backward()
     model(x).pow(2).sum().backward()
     launched_in_backward = sum(flat2._launched)
+    assert not flat2._launched[-1]                       # the range with the unused parameter waits for finish()
     flat2.finish()
     got2 = torch.cat([p.grad.reshape(-1) for p in params])
     ok_grad = ok_grad and torch.allclose(got2, want, atol=1e-6) and bool((unused.grad == 0).all()) \
