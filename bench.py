@@ -37,7 +37,7 @@ VALU_PEAK_TF = 157.3        # fp32 vector peak
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak
 
 
-def cpu_baseline(seconds_budget=40.0):
+def cpu_baseline(seconds_budget=40.0, eval_root=None):
     """The oracle's full training step on the host CPU: B=2, 192x640, fp32 (config 1)."""
     import types
     from oracle import model_spec, ref_model, synth          # the CPU baseline IS the oracle
@@ -49,7 +49,23 @@ def cpu_baseline(seconds_budget=40.0):
           for k, (shape, dt) in model_spec.state_spec("b").items()}
     sd = ref_model.leaf_state_dict(sd, opt)
     tr = ref_model.RefTrainer(ref_model.RefRepDepth(sd, opt), opt)
+    torch.set_num_threads(min(torch.get_num_threads(), 16))
+    absrel_oracle = None
+    if eval_root is not None:      # before the training forwards below move the BN running statistics
+        # AbsRel of the oracle's eval-mode inference path on the synthetic eigen_zhou-format split (the checker for
+        # the "absrel" object of the bench line; pinned to the reference's Trainer.val by tests/golden/eval.npz)
+        from oracle import ref_ops as R
+        ds = synth.SynthEigenDataset(eval_root, split="eigen", height=H, width=W)
+        batch = synth.collate([ds[i] for i in range(len(ds))])
+        model = ref_model.RefRepDepth({k: v.detach() for k, v in sd.items()}, opt)
+        model.training = False
+        disp, mono = model.predict_val(batch, torch.tensor([0.1]), torch.tensor([10.0]))
+        gts = ds.gt_depths()
+        absrel_oracle = round(float(torch.stack(
+            [R.evaluate_image(disp[i], torch.from_numpy(gts[i])) for i in range(len(gts))]).mean(0)[0]), 5)
     inputs = synth.make_inputs(B, H, W)
+    # a GPU box shows every host core but grants a 16-core share: more threads than that only oversubscribe
+    torch.set_num_threads(min(torch.get_num_threads(), 16))
     cores = torch.get_num_threads()
     times = []
     t_all = time.time()
@@ -64,9 +80,12 @@ def cpu_baseline(seconds_budget=40.0):
         if time.time() - t_all > seconds_budget:
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": round(B / best, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": f"{len(times)} x (process_batch + backward), B=2, 192x640, RepLKNet-31B fp32, "
-                      f"torch-CPU oracle, best of the non-first iterations ({best:.2f} s/step)"}
+    out = {"value": round(B / best, 4), "unit": "img/s", "cores": cores, "kind": "port",
+           "sample": f"{len(times)} x (process_batch + backward), B=2, 192x640, RepLKNet-31B fp32, "
+                     f"torch-CPU oracle, best of the non-first iterations ({best:.2f} s/step)"}
+    if absrel_oracle is not None:
+        out["absrel_oracle"] = absrel_oracle
+    return out
 
 
 def main():
@@ -245,13 +264,38 @@ def main():
         watchdog = threading.Timer(deadline, on_timeout)
         watchdog.daemon = True
 
+    def absrel(eval_root):
+        """AbsRel (BASELINE metric, second half) of this build on a synthetic eigen_zhou-format split with the
+        benchmark's random-init weights restored to their initial values is not possible after training steps, so a
+        fresh model with the same synthetic weights is evaluated: fp32 and the benchmarked bf16 arithmetic."""
+        synth.make_eval_split(eval_root, n=2, height=H, width=W, seed=7, split="eigen")
+        ds = synth.SynthEigenDataset(eval_root, split="eigen", height=H, width=W)
+        batch = synth.collate([ds[i] for i in range(len(ds))])
+        eopt = options.default_options(height=H, width=W, batch_size=len(ds), rep_size=args.rep_size)
+        emodel = networks.RepDepth(eopt)
+        synth.fill_state_dict(emodel)
+        emodel.to(device)
+        etr = Trainer(eopt, emodel, device)
+        res = {"split": "synthetic eigen_zhou-format (2 frames, 375x1242 sparse ground truth)", "weights": "random init"}
+        res["fp32"] = round(float(etr.val([batch], ds.gt_depths())[0][0]), 5)
+        etr.amp_dtype = torch.bfloat16
+        res["bf16"] = round(float(etr.val([batch], ds.gt_depths())[0][0]), 5)
+        return res
+
     def emit(dt, loss_val, eager, launch, hang=False):
         line = make_line(dt, loss_val, launch)
         if hang:
             line["hang"] = True
         if world == 1 and not args.no_cpu_baseline:
+            import tempfile
+            eval_root = tempfile.mkdtemp(prefix="ppea_eval_") if args.rep_size == "b" else None
             try:
-                line["cpu_baseline"] = cpu_baseline()
+                if eval_root is not None:
+                    line["absrel"] = absrel(eval_root)
+                line["cpu_baseline"] = cpu_baseline(eval_root=eval_root)
+                if eval_root is not None and "absrel_oracle" in line["cpu_baseline"]:
+                    line["absrel"]["oracle_cpu"] = line["cpu_baseline"]["absrel_oracle"]
+                    line["absrel"]["abs_diff_fp32"] = round(abs(line["absrel"]["fp32"] - line["absrel"]["oracle_cpu"]), 6)
             except Exception as ex:          # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(line), flush=True)

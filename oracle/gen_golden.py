@@ -298,6 +298,41 @@ def gen_e2e(name, B, H, W, extra=(), stride=1, seed=1, grad_keys=None, intrinsic
     save(name, **arrays)
 
 
+def gen_eval():
+    """(1) evaluate_depth.compute_errors on fixed arrays; (2) the reference's unmodified `Trainer.val`
+    (trainer.py:653-857) on a synthetic eigen_zhou-format split (synth.make_eval_split), synthetic weights, eval
+    mode: mean errors of the multi-frame network and of the teacher + the predicted disparities."""
+    import tempfile
+    from ppeadepth.evaluate_depth import compute_errors
+    g = torch.Generator().manual_seed(3)
+    gt = (1.0 + 60 * torch.rand(5000, generator=g)).numpy().astype(np.float64)
+    pred = (gt * (0.7 + 0.6 * torch.rand(5000, generator=g).numpy())).astype(np.float64)
+    arrays = {"ce_gt": gt, "ce_pred": pred, "ce_errors": np.array(compute_errors(gt, pred))}
+    n, H, W = 3, 192, 640
+    opt = rh.parse_options(["--height", str(H), "--width", str(W), "--batch_size", str(n), "--eval_split", "eigen"])
+    torch.manual_seed(0)
+    with rh.scratch_cwd():
+        from ppeadepth import networks
+        model = networks.RepDepth(opt)
+    synth.fill_state_dict(model)
+    model.eval()
+    tr = rh.build_reference_trainer(opt, model)
+    tr.model = types.SimpleNamespace(module=model)
+    tr.val_frames_to_load = [0, -1]
+    root = tempfile.mkdtemp(prefix="ppea_eval_")
+    synth.make_eval_split(root, n=n, height=H, width=W, seed=7, split="eigen")
+    ds = synth.SynthEigenDataset(root, split="eigen", height=H, width=W)
+    tr.val_loader = [synth.collate([ds[i] for i in range(n)])]
+    old = os.getcwd()
+    os.chdir(root)
+    try:
+        errors, errors_mono = tr.val()
+    finally:
+        os.chdir(old)
+    arrays.update(val_meta=np.array([n, H, W, 7]), val_errors=np.asarray(errors), val_errors_mono=np.asarray(errors_mono))
+    save("eval", **arrays)
+
+
 def gen_state_spec():
     """Key names / shapes / trainable flags of RepDepth(opt).state_dict() (31B and 31L)."""
     arrays = {}
@@ -319,6 +354,7 @@ def gen_state_spec():
 
 GENERATORS = {
     "state_spec": gen_state_spec,
+    "eval": gen_eval,
     "layers_geometry": gen_layers,
     "losses": gen_losses,
     "replk_blocks": gen_replk_blocks,

@@ -176,7 +176,15 @@ def install_stubs():
     transforms = _module("torchvision.transforms", ColorJitter=_T, ToTensor=_T,
                          Resize=_T, InterpolationMode=types.SimpleNamespace(LANCZOS=1))
     _module("torchvision", models=models, transforms=transforms)
-    _module("cv2", setNumThreads=lambda n: None)
+    def _cv2_resize(img, dsize, interpolation=None):
+        """cv2.resize with the default INTER_LINEAR on a 2-D float array (trainer.py:793): bilinear, half-pixel
+        centres, no antialiasing."""
+        import numpy as np
+        import torch.nn.functional as F
+        t = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))[None, None]
+        return F.interpolate(t, (dsize[1], dsize[0]), mode="bilinear", align_corners=False)[0, 0].numpy()
+
+    _module("cv2", setNumThreads=lambda n: None, resize=_cv2_resize)
     _module("wandb", init=lambda *a, **k: None, log=lambda *a, **k: None)
     _module("torchmetrics", Metric=_Metric)
     sk_t = _module("skimage.transform")

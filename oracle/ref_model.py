@@ -47,10 +47,14 @@ class RefRepDepth:
         # dpr: torch.linspace(0, rate, sum(layers)) (replknet_adapter.py:425)
         self.dpr = [x.item() for x in torch.linspace(0, DROP_PATH_RATE, n)]
         self.bn_updates = 1     # 2 inside checkpointed segments (reentrant recompute)
+        self.training = True    # False: model.eval() -- BN on running statistics, DropPath off (Trainer.val)
 
     # ----- primitives -------------------------------------------------------
     def _bn(self, x, p, twice=False):
         sd = self.sd
+        if not self.training:
+            return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"],
+                                sd[p + ".bias"], False, 0.1, 1e-5)
         y = F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"],
                          sd[p + ".bias"], True, 0.1, 1e-5)
         if twice and torch.is_grad_enabled() and self.opt.use_checkpoint:
@@ -70,7 +74,7 @@ class RefRepDepth:
         return F.relu(y) if relu else y
 
     def _drop_path(self, x, p):
-        if p == 0.0:
+        if p == 0.0 or not self.training:
             return x
         return x * R.drop_path_mask(x.shape[0], p)
 
@@ -234,6 +238,21 @@ class RefRepDepth:
             pose = pose * (~empty).float()[:, None, None]
             inputs[("relative_pose", -1)] = pose
         return outputs
+
+    # ----- inference path of Trainer.val (trainer.py:676-752), model.eval() ------------------
+    @torch.no_grad()
+    def predict_val(self, data, min_bin, max_bin, max_depth=100.0):
+        """-> (scaled multi-frame disparity [B,H,W], scaled teacher disparity [B,H,W])."""
+        assert not self.training
+        c0, cm1 = data[("color", 0, 0)], data[("color", -1, 0)]
+        aa, tt = self.pose_net(torch.cat([cm1, c0], 1))
+        pose = R.transformation_from_parameters(aa[:, 0], tt[:, 0], invert=True)
+        data[("relative_pose", -1)] = pose
+        feats, _lowest, _conf, _idx = self.matching_encoder(c0, cm1[:, None], pose[:, None], data[("K", 2)],
+                                                            data[("inv_K", 2)], min_bin, max_bin)
+        disp, _ = R.disp_to_depth(self.depth_decoder(feats, "depth"), 1e-3, 80)
+        mono, _ = R.disp_to_depth(self.depth_decoder(self.mono_encoder(c0), "mono_depth"), 1e-3, max_depth)
+        return disp[:, 0], mono[:, 0]
 
     # ----- RepDepth.forward (repdepth.py:529-624) ------------------------------
     def forward(self, inputs, min_bin, max_bin):

@@ -374,3 +374,40 @@ def drop_path_mask(batch, drop_prob, generator=None):
 
 def gelu_exact(x):
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+# ---------------------------------------------------------------------------------------------
+# depth metrics: evaluate_depth.py:35-54 and the per-image protocol of Trainer.val (trainer.py:780-835)
+# ---------------------------------------------------------------------------------------------
+def compute_errors(gt, pred):
+    """gt, pred: 1-D float tensors of valid pixels -> (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3)."""
+    gt, pred = gt.double(), pred.double()
+    thresh = torch.maximum(gt / pred, pred / gt)
+    a = [(thresh < 1.25 ** k).double().mean() for k in (1, 2, 3)]
+    rmse = ((gt - pred) ** 2).mean().sqrt()
+    rmse_log = ((gt.log() - pred.log()) ** 2).mean().sqrt()
+    abs_rel = ((gt - pred).abs() / gt).mean()
+    sq_rel = ((gt - pred) ** 2 / gt).mean()
+    return torch.stack([abs_rel, sq_rel, rmse, rmse_log] + a)
+
+
+def evaluate_image(pred_disp, gt_depth, min_val=1e-3, max_val=80.0):
+    """pred_disp [h,w], gt_depth [H,W] (0 = no return), eval_split "eigen": bilinear resize of the disparity to the
+    ground-truth size (cv2.resize INTER_LINEAR), Garg/Eigen crop, median scaling, clamp."""
+    H, W = gt_depth.shape
+    pd = 1 / F.interpolate(pred_disp[None, None].float(), (H, W), mode="bilinear", align_corners=False)[0, 0]
+    mask = (gt_depth > min_val) & (gt_depth < max_val)
+    crop = torch.zeros_like(mask)
+    y0, y1, x0, x1 = int(0.40810811 * H), int(0.99189189 * H), int(0.03594771 * W), int(0.96405229 * W)
+    crop[y0:y1, x0:x1] = True
+    mask = mask & crop
+    pd, gt = pd[mask], gt_depth[mask]
+    pd = pd * (gt.median() if gt.numel() % 2 else _np_median(gt)) / (pd.median() if pd.numel() % 2 else _np_median(pd))
+    return compute_errors(gt, pd.clamp(min_val, max_val))
+
+
+def _np_median(t):
+    """numpy's median of an even-length array is the mean of the two middle values (torch takes the lower one)."""
+    s = t.sort()[0]
+    n = s.numel()
+    return (s[n // 2 - 1] + s[n // 2]) / 2

@@ -498,9 +498,26 @@ class RepLKNetAdapter(nn.Module):
         return self.forward_features(x)
 
     def structural_reparam(self):
+        """rka.py:544-547 / replknet.py:400-413: every k x k + 5 x 5 branch pair (with its two BNs) becomes ONE k x k
+        depthwise conv with bias -- inference only (uses the running statistics)."""
         for m in self.modules():
             if hasattr(m, "merge_kernel"):
                 m.merge_kernel()
+
+    def deep_fuse_BN(self):
+        """rka.py:563-580: fold the BN of every remaining conv-BN(-ReLU) `nn.Sequential` into its conv (inference)."""
+        for m in self.modules():
+            if not isinstance(m, nn.Sequential) or len(m) not in (2, 3):
+                continue
+            if hasattr(m[0], "kernel_size") and hasattr(m[0], "weight") and isinstance(m[1], (BatchNorm2d, nn.BatchNorm2d)):
+                conv, bn = m[0], m[1]
+                fused_kernel, fused_bias = fuse_bn(conv, bn)
+                fused_conv = get_conv2d(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.stride[0],
+                                        conv.padding[0], conv.dilation[0], conv.groups, True)
+                fused_conv.weight.data = fused_kernel.detach()
+                fused_conv.bias.data = fused_bias.detach()
+                m[0] = fused_conv
+                m[1] = nn.Identity()
 
 
 def _factory(channels):

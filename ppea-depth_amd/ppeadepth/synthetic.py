@@ -109,3 +109,112 @@ def make_inputs(batch: int, height: int, width: int, seed: int = 1234,
         inputs[("K", s)] = K[None].repeat(batch, 1, 1).contiguous()
         inputs[("inv_K", s)] = inv_K[None].repeat(batch, 1, 1).contiguous()
     return inputs
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic validation split in the eigen_zhou on-disk format (kitti_dataset.py:46-62, trainer.py:766-767)
+# ---------------------------------------------------------------------------------------------
+def _scene(index, height, width, seed):
+    """(texture [3,H,W] in [0,1], depth [H,W] in metres): a ground plane receding to the horizon plus smooth blobs."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed * 1000 + index)
+    k = torch.ones(3, 1, 15, 15) / 225.0
+    tex = torch.rand(1, 3, height + 14, width + 14, generator=g)
+    tex = torch.nn.functional.conv2d(tex, k, groups=3)[0]
+    tex = (tex - tex.amin()) / (tex.amax() - tex.amin() + 1e-6)
+    ys = torch.linspace(0, 1, height)[:, None].expand(height, width)
+    ground = 1.6 / (0.04 + 0.9 * (ys - 0.35).clamp_min(0.0))            # camera 1.6 m above the road
+    sky = torch.full_like(ground, 70.0)
+    depth = torch.where(ys > 0.37, ground.clamp(max=70.0), sky)
+    blobs = torch.rand(1, 1, height // 16 + 1, width // 16 + 1, generator=g)
+    blobs = torch.nn.functional.interpolate(blobs, (height, width), mode="bilinear", align_corners=False)[0, 0]
+    depth = (depth * (0.6 + 0.5 * blobs)).clamp(1.5, 75.0)
+    return tex, depth
+
+
+def _render_neighbour(tex, depth, K, inv_K, tz):
+    """Frame seen after moving the camera `tz` metres along its axis: inverse warp of the centre frame with its own
+    depth (a first-order rendering: exact for fronto-parallel surfaces, good enough for synthetic data)."""
+    H, W = depth.shape
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    pix = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(H * W)], 0)
+    cam = (inv_K[:3, :3] @ pix) * depth.reshape(1, -1)
+    cam[2] += tz
+    proj = K[:3, :3] @ cam
+    u = proj[0] / proj[2].clamp_min(1e-3) / (W - 1) * 2 - 1
+    v = proj[1] / proj[2].clamp_min(1e-3) / (H - 1) * 2 - 1
+    grid = torch.stack([u, v], -1).reshape(1, H, W, 2)
+    return torch.nn.functional.grid_sample(tex[None], grid, padding_mode="border", align_corners=True)[0]
+
+
+def make_eval_split(root, n=4, height=192, width=640, gt_hw=(375, 1242), seed=7, split="eigen_zhou_synth"):
+    """Writes an eigen_zhou-format split under `root`:
+         splits/<split>/val_files.txt      lines "<folder> <frame index> <l|r>"   (kitti_dataset.py:46-62)
+         splits/<split>/gt_depths.npz      ["data"]: object array of [375,1242] float32 maps, 0 = no LiDAR return
+         <folder>/image_02/data/<%010d>.npy frames t-1, t, t+1 as float32 [3,H,W] in [0,1]
+       and returns the list of split lines."""
+    import os
+    os.makedirs(os.path.join(root, "splits", split), exist_ok=True)
+    K, inv_K = kitti_K(height, width, 0)
+    lines, gts = [], []
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    for i in range(n):
+        folder = f"synth_2011_09_26/synth_drive_{i:04d}_sync"
+        frame = 5 + i
+        tex, depth = _scene(i, height, width, seed)
+        d = os.path.join(root, folder, "image_02", "data")
+        os.makedirs(d, exist_ok=True)
+        frames = {0: tex, -1: _render_neighbour(tex, depth, K, inv_K, -0.4), 1: _render_neighbour(tex, depth, K, inv_K, 0.4)}
+        for off, img in frames.items():
+            np.save(os.path.join(d, f"{frame + off:010d}.npy"), img.numpy().astype(np.float32))
+        gt = torch.nn.functional.interpolate(depth[None, None], gt_hw, mode="bilinear", align_corners=False)[0, 0]
+        keep = torch.rand(gt_hw, generator=g) < 0.05                      # LiDAR-like sparsity
+        gts.append((gt * keep).numpy().astype(np.float32))
+        lines.append(f"{folder} {frame} l")
+    with open(os.path.join(root, "splits", split, "val_files.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    arr = np.empty(len(gts), dtype=object)
+    for i, gmap in enumerate(gts):
+        arr[i] = gmap
+    np.savez_compressed(os.path.join(root, "splits", split, "gt_depths.npz"), data=arr)
+    return lines
+
+
+class SynthEigenDataset(torch.utils.data.Dataset):
+    """Reads a split written by `make_eval_split` the way KITTIRAWDataset reads eigen_zhou (kitti_dataset.py:46-62,
+    mono_dataset.py:120-201, is_train=False: no augmentation): items are row-P dictionaries."""
+
+    def __init__(self, root, split="eigen_zhou_synth", height=192, width=640, frame_idxs=(0, -1, 1), num_scales=4):
+        import os
+        self.root, self.height, self.width = root, height, width
+        self.frame_idxs, self.num_scales = tuple(frame_idxs), num_scales
+        with open(os.path.join(root, "splits", split, "val_files.txt")) as f:
+            self.filenames = f.read().splitlines()
+        self.gt_path = os.path.join(root, "splits", split, "gt_depths.npz")
+
+    def __len__(self):
+        return len(self.filenames)
+
+    def gt_depths(self):
+        return np.load(self.gt_path, fix_imports=True, encoding="latin1", allow_pickle=True)["data"]
+
+    def __getitem__(self, index):
+        import os
+        folder, frame, _side = self.filenames[index].split()
+        inputs = {}
+        for f in self.frame_idxs:
+            path = os.path.join(self.root, folder, "image_02", "data", f"{int(frame) + f:010d}.npy")
+            img = torch.from_numpy(np.load(path)) if os.path.exists(path) else torch.zeros(3, self.height, self.width)
+            for s in range(self.num_scales):
+                t = img if s == 0 else torch.nn.functional.avg_pool2d(img[None], 2 ** s)[0]
+                inputs[("color", f, s)] = t
+                inputs[("color_aug", f, s)] = t
+        for s in range(self.num_scales):
+            K, inv_K = kitti_K(self.height, self.width, s)
+            inputs[("K", s)], inputs[("inv_K", s)] = K, inv_K
+        return inputs
+
+
+def collate(items):
+    return {k: torch.stack([it[k] for it in items]) for k in items[0]}

@@ -19,6 +19,9 @@ from . import ops, rng
 from .layers import disp_to_depth
 
 
+MIN_VAL_EVAL = 1e-3          # trainer.py:657
+
+
 class DepthBins:
     """trainer.py:41-69 -- EMA(0.99) tracker of the teacher's depth range.  The state is two persistent
     0-dim device tensors that are only ever updated IN PLACE: a captured step graph reads and writes the
@@ -133,6 +136,63 @@ class Trainer:
             self.acc.wait_for_everyone()
             tracker.update(outputs[("mono_depth", 0, 0)])
         return outputs, losses
+
+    # ---- trainer.py:653-857 -----------------------------------------------------------------------
+    @torch.no_grad()
+    def predict_disps(self, data, mono=True):
+        """Inference path of `val` for one batch (trainer.py:676-752): pose of the lookup frame from the pose network,
+        cost volume + multi-frame encoder + decoder, optionally the single-frame teacher; model in eval mode.
+        -> (scaled multi-frame disparity [B,H,W], scaled teacher disparity or None), as `disp_to_depth(., 1e-3, 80)`."""
+        from .layers import transformation_from_parameters
+        model = self._module()
+        dev = self.device
+        ctx = torch.autocast("cuda", dtype=self.amp_dtype) if self.amp_dtype is not None else contextlib.nullcontext()
+        color = {f: data[("color", f, 0)].to(dev) for f in (0, -1)}
+        with ctx:
+            feats = [model.pose_encoder(torch.cat([color[-1], color[0]], 1))]
+            axisangle, translation = model.pose(feats)
+            pose = transformation_from_parameters(axisangle[:, 0].float(), translation[:, 0].float(), invert=True)
+            data[("relative_pose", -1)] = pose
+            tracker = self.depth_bin_tracker
+            if getattr(self.opt, "notadabins", False):
+                mn, mx = tracker.min_depth, tracker.max_depth
+            else:
+                mn, mx = tracker.compute()
+            feats, _lowest, _conf = model.encoder(color[0], color[-1][:, None], pose[:, None],
+                                                  data[("K", 2)].to(dev), data[("inv_K", 2)].to(dev), mn, mx)
+            disp = model.depth(feats)[("disp", 0)].float()
+            pred, _ = disp_to_depth(disp, MIN_VAL_EVAL, 80)
+            pred_mono = None
+            if mono:
+                dm = model.mono_depth(model.mono_encoder(color[0]))[("disp", 0)].float()
+                pred_mono, _ = disp_to_depth(dm, MIN_VAL_EVAL, self.opt.max_depth)
+                pred_mono = pred_mono[:, 0]
+        return pred[:, 0], pred_mono
+
+    def val(self, batches, gt_depths, eval_split="eigen", hard_test_mono=False, median_scaling=True):
+        """`Trainer.val` (trainer.py:653-857) over an iterable of row-P batches and the split's ground-truth depth
+        maps (`gt_depths.npz["data"]`, trainer.py:766-767): mean of (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3) for
+        the multi-frame network and, unless the teacher is frozen, for the teacher."""
+        import numpy as np
+        from . import evaluate
+        model = self._module()
+        was_training = model.training
+        model.eval()
+        mono_flag = (not self.freeze_tp) or hard_test_mono
+        disps, disps_mono = [], []
+        try:
+            for data in batches:
+                d, dm = self.predict_disps(data, mono_flag)
+                disps.append(d.cpu().numpy())
+                if mono_flag:
+                    disps_mono.append(dm.cpu().numpy())
+        finally:
+            model.train(was_training)
+        disps = np.concatenate(disps)
+        mean_errors = evaluate.evaluate_disps(disps, gt_depths, eval_split, median_scaling)
+        if mono_flag:
+            return mean_errors, evaluate.evaluate_disps(np.concatenate(disps_mono), gt_depths, eval_split, True)
+        return mean_errors
 
     # ---- trainer.py:859-869 -----------------------------------------------------------------------
     def compute_matching_mask(self, outputs):

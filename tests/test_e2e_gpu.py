@@ -421,3 +421,48 @@ def test_graph_replay_equals_eager_steps_with_adaptive_bins(device, bf16):
     assert moved, "tracker state did not move across replays"
     assert graph[-1][2] != graph[0][2], "bins frozen across replays"
     assert rel_err(w1, w0) < (5e-2 if bf16 else 2e-2)
+
+
+# ---- AbsRel harness (north_star: AbsRel within +-0.001 of the reference) --------------------------
+def test_val_absrel_matches_reference_on_synthetic_eigen_split(device, golden, tmp_path):
+    """`Trainer.val` of this build (GPU inference in eval mode: pose of the lookup frame, cost volume, multi-frame
+    encoder + decoder, teacher) on the synthetic eigen_zhou-format split against the reference's own `Trainer.val`
+    (tests/golden/eval.npz): |AbsRel - AbsRel_ref| <= 1e-3 for both networks in fp32, all seven metrics within 1e-3
+    relative.  bf16 inference (the benchmarked arithmetic) is reported against the same bound x10: eval-mode BN uses
+    running statistics, so the network is far less chaotic than the training step (see the bf16 step test)."""
+    import numpy as np
+    g = golden("eval")
+    n, H, W, seed = (int(v) for v in g["val_meta"])
+    synth.make_eval_split(str(tmp_path), n=n, height=H, width=W, seed=seed, split="eigen")
+    ds = synth.SynthEigenDataset(str(tmp_path), split="eigen", height=H, width=W)
+    opt, model, tr = _build(device, n, H, W)
+    err, err_m = tr.val([synth.collate([ds[i] for i in range(n)])], ds.gt_depths())
+    assert abs(err[0] - float(g["val_errors"][0])) <= 1e-3, (err[0], float(g["val_errors"][0]))
+    assert abs(err_m[0] - float(g["val_errors_mono"][0])) <= 1e-3
+    assert np.allclose(err, g["val_errors"].numpy(), rtol=1e-3) and np.allclose(err_m, g["val_errors_mono"].numpy(), rtol=1e-3)
+    assert model.training                                         # val() restores the mode it found
+    tr.amp_dtype = torch.bfloat16
+    err16, err16_m = tr.val([synth.collate([ds[i] for i in range(n)])], ds.gt_depths())
+    assert abs(err16[0] - float(g["val_errors"][0])) <= 1e-2, (err16[0], float(g["val_errors"][0]))
+    assert abs(err16_m[0] - float(g["val_errors_mono"][0])) <= 1e-2, (err16_m[0], float(g["val_errors_mono"][0]))
+
+
+def test_device_input_pipeline_feeds_process_batch(device):
+    """SURVEY 8(f)-3 on the GPU: the device pyramid equals the CPU evaluation of the same pipeline byte for byte (which
+    tests/test_host_cpu.py pins to Pillow's LANCZOS), and its row-P dictionary drives `process_batch`."""
+    from ppeadepth import input_pipeline as ip
+    g = torch.Generator().manual_seed(0)
+    Hr, Wr, H, W, B = 96, 320, 64, 96, 2
+    raw = {f: torch.randint(0, 256, (B, 3, Hr, Wr), generator=g, dtype=torch.uint8) for f in (0, -1, 1)}
+    flip, aug = torch.tensor([True, False]), torch.tensor([True, False])
+    jit = ip.draw_jitter_params(B, g)
+    out_d = ip.DeviceInputPipeline((Hr, Wr), H, W, device)(raw, aug, flip, jit)
+    out_c = ip.DeviceInputPipeline((Hr, Wr), H, W, "cpu")(raw, aug, flip, jit)
+    for k, v in out_c.items():
+        if k[0] == "color":
+            assert torch.equal(out_d[k].cpu(), v), k
+        else:
+            assert torch.allclose(out_d[k].cpu(), v, atol=2e-6), k
+    opt, model, tr = _build(device, B, H, W)
+    outputs, losses = tr.process_batch(out_d, True)
+    assert torch.isfinite(losses["loss"]).item() and outputs[("disp", 0)].shape == (B, 1, H, W)

@@ -298,3 +298,79 @@ def test_pose_trunk_group_bn_and_pass_replay_cpu():
                 assert rel_err(cand[k], v) < 2e-4, (name, k)
             elif "num_batches_tracked" in k:
                 assert int(cand[k]) == int(v) == 3, (name, k)
+
+
+def test_merge_kernel_and_fuse_bn_equivalent_kernels_cpu():
+    """Inference-time re-parameterisation (rka.py:199-208, 241-261): the merged k x k kernel + bias equals
+    BN(conv_k(x)) + BN(conv_5(x)) with running statistics -- checked with plain F.conv2d on the module's tensors (the
+    module's own forward needs the HIP kernels)."""
+    import torch.nn.functional as F
+    from oracle import synth
+    from ppeadepth.networks import replknet_adapter as rka
+    C, K = 6, 13
+    m = rka.ReparamLargeKernelConv(C, C, K, 1, C, small_kernel=5).eval()
+    synth.fill_state_dict(m)
+    x = torch.randn(2, C, 9, 11)
+
+    def bn(z, b):
+        return F.batch_norm(z, b.running_mean, b.running_var, b.weight, b.bias, False, 0.0, b.eps)
+    want = bn(F.conv2d(x, m.lkb_origin.conv.weight, None, 1, K // 2, 1, C), m.lkb_origin.bn) + \
+        bn(F.conv2d(x, m.small_conv.conv.weight, None, 1, 2, 1, C), m.small_conv.bn)
+    m.merge_kernel()
+    assert not hasattr(m, "lkb_origin") and not hasattr(m, "small_conv")
+    assert type(m.lkb_reparam).__name__ == "LargeKernelDW" and m.lkb_reparam.bias is not None
+    got = F.conv2d(x, m.lkb_reparam.weight, m.lkb_reparam.bias, 1, K // 2, 1, C)
+    assert rel_err(got, want) < 1e-5
+    assert list(m.state_dict().keys()) == ["lkb_reparam.weight", "lkb_reparam.bias"]
+
+
+def _load_by_path(name):
+    """Product modules that are pure torch / numpy, loaded by path (the package __init__ chain needs the HIP library
+    only for `ops`; these do not touch it)."""
+    import importlib.util
+    from conftest import PKG
+    spec = importlib.util.spec_from_file_location("_ppea_" + name, os.path.join(PKG, "ppeadepth", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_device_input_pipeline_pyramid_is_bit_exact_with_pillow_lanczos():
+    """the device pyramid (fp64 GEMMs over Pillow's fixed-point coefficients) against Pillow's own
+    `Image.resize(..., LANCZOS)` chained scale to scale like mono_dataset.py:96-101 -- every byte equal; plus the row-P
+    contract of the produced dictionary (keys, shapes, intrinsics of mono_dataset.py:173-182, flip, blank frames)."""
+    from PIL import Image
+    ip = _load_by_path("input_pipeline")
+    g = torch.Generator().manual_seed(0)
+    Hr, Wr, H, W, B = 375, 1242, 192, 640, 2
+    raw = {f: torch.randint(0, 256, (B, 3, Hr, Wr), generator=g, dtype=torch.uint8) for f in (0, -1, 1)}
+    raw[1][1] = 0                                                       # a missing neighbour (mono_dataset.py:160-164)
+    pipe = ip.DeviceInputPipeline((Hr, Wr), H, W, "cpu")
+    flip = torch.tensor([False, True])
+    aug = torch.tensor([True, True])
+    out = pipe(raw, do_color_aug=aug, do_flip=flip, generator=g)
+    for f in (0, -1, 1):
+        for b in range(B):
+            im = Image.fromarray(raw[f][b].permute(1, 2, 0).numpy())
+            if bool(flip[b]):
+                im = im.transpose(Image.FLIP_LEFT_RIGHT)
+            for s in range(4):
+                im = im.resize((W // 2 ** s, H // 2 ** s), Image.LANCZOS)
+                want = torch.from_numpy(np.asarray(im)).permute(2, 0, 1)
+                got = (out[("color", f, s)][b] * 255.0).round().to(torch.uint8)
+                assert torch.equal(got, want), (f, b, s, int((got.int() - want.int()).abs().max()))
+    assert out[("color_aug", 0, 0)].shape == (B, 3, H, W) and out[("color", 0, 3)].shape == (B, 3, H // 8, W // 8)
+    assert float((out[("color_aug", 0, 0)] - out[("color", 0, 0)]).abs().max()) > 1e-3     # jitter applied
+    assert torch.equal(out[("color_aug", 1, 0)][1], out[("color", 1, 0)][1])               # blank frame: no jitter
+    from oracle import synth
+    for s in range(4):
+        K, inv_K = synth.kitti_K(H, W, s)
+        assert torch.allclose(out[("K", s)][0], K) and torch.allclose(out[("inv_K", s)][1], inv_K, atol=1e-6)
+    # colour operations against closed forms: factor 1 / hue 0 are identities, brightness scales
+    img = torch.rand(2, 3, 8, 8, generator=g)
+    one = torch.ones(2, 1, 1, 1)
+    for fn in (ip.adjust_brightness, ip.adjust_contrast, ip.adjust_saturation):
+        assert torch.allclose(fn(img, one), img, atol=1e-6)
+    assert torch.allclose(ip.adjust_hue(img, torch.zeros(2)), img, atol=1e-5)
+    assert torch.allclose(ip.adjust_brightness(img, 0.5 * one), 0.5 * img, atol=1e-6)
+    assert torch.allclose(ip.adjust_hue(ip.adjust_hue(img, torch.full((2,), 0.3)), torch.full((2,), -0.3)), img, atol=1e-4)

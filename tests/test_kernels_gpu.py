@@ -701,3 +701,31 @@ def test_replk_modules_bf16_vs_oracle(device, kind, C, K, H, W):
     for n in names:
         e, et = _l2(dw[n].float().cpu(), sd["m." + n].grad), _l2(dw_t[n].float().cpu(), sd["m." + n].grad)
         assert e < 1.5 * et + 1e-2 and e < 0.3, (n, e, et)
+
+
+def test_structural_reparam_and_deep_fuse_bn_equivalence(device):
+    """SURVEY 8(f)-4, the reference's own check (replknet.py:400-413): eval forward of a RepLKNet-adapter backbone before
+    and after `structural_reparam()` (merged 31/29/27/13 convs with bias on the `dwconv_lk` kernel) and after
+    `deep_fuse_BN()` (rka.py:563-580) gives the same four feature maps."""
+    from oracle import synth
+    from ppeadepth.networks import replknet_adapter as rka
+    net = rka.RepLKNetAdapter([31, 29, 27, 13], [1, 1, 2, 1], [32, 64, 96, 128], 0.3, 5, num_classes=None,
+                              out_indices=(0, 1, 2, 3), use_checkpoint=False, use_sync_bn=False, adpt_test=4)
+    synth.fill_state_dict(net)
+    net.to(device).eval()
+    x = torch.rand(2, 3, 64, 96, generator=_g(3)).to(device)
+    with torch.no_grad():
+        base = [f.clone() for f in net(x)]
+        net.structural_reparam()
+        merged = [m for m in net.modules() if isinstance(m, rka.ReparamLargeKernelConv)]
+        assert merged and all(type(m.lkb_reparam).__name__ == "LargeKernelDW" and m.lkb_reparam.bias is not None
+                              for m in merged)
+        after = net(x)
+        for a, b in zip(after, base):
+            assert rel_err(a, b) < 1e-4
+        net.deep_fuse_BN()
+        assert not any(isinstance(m[1], rka.BatchNorm2d) for m in net.modules()
+                       if isinstance(m, torch.nn.Sequential) and len(m) in (2, 3) and hasattr(m[0], "kernel_size"))
+        fused = net(x)
+        for a, b in zip(fused, base):
+            assert rel_err(a, b) < 1e-4

@@ -3,6 +3,7 @@ produced by the reference implementation itself (oracle/gen_golden.py).
 
 Tolerances: fp32 outputs <= 1e-5 relative, index tensors bit-exact.
 """
+import os
 import random
 import types
 
@@ -260,3 +261,54 @@ def test_state_spec_matches_reference(size):
             continue
         assert RM.trainable(n, opt) == bool(t), n
     assert list(z[f"{size}:bn_types"]) == ["BatchNorm2d", "SyncBatchNorm"]
+
+
+# ---------------------------------------------------------------------------
+# AbsRel harness
+# ---------------------------------------------------------------------------
+def _eval_split(tmp_path, g):
+    n, H, W, seed = (int(v) for v in g["val_meta"])
+    synth.make_eval_split(str(tmp_path), n=n, height=H, width=W, seed=seed, split="eigen")
+    ds = synth.SynthEigenDataset(str(tmp_path), split="eigen", height=H, width=W)
+    return ds, synth.collate([ds[i] for i in range(n)])
+
+
+def test_compute_errors_matches_reference(golden):
+    """Oracle restatement and the product's numpy `compute_errors` against the reference's own
+    evaluate_depth.compute_errors on fixed arrays (tests/golden/eval.npz)."""
+    g = golden("eval")
+    assert rel_err(R.compute_errors(g["ce_gt"], g["ce_pred"]), g["ce_errors"]) < 1e-9
+    import importlib.util
+    import numpy as np
+    from conftest import PKG
+    spec = importlib.util.spec_from_file_location("_ppea_evaluate", os.path.join(PKG, "ppeadepth", "evaluate.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)                                   # by path: no HIP library needed for the metric code
+    mine = np.array(ev.compute_errors(g["ce_gt"].numpy(), g["ce_pred"].numpy()))
+    assert np.allclose(mine, g["ce_errors"].numpy(), rtol=1e-12)
+    # the per-image protocol (resize, Eigen crop, median scaling, clamp): product numpy == oracle torch
+    gen = torch.Generator().manual_seed(5)
+    disp = 1 / (2 + 50 * torch.rand(48, 160, generator=gen))
+    gt = (1 + 70 * torch.rand(375, 1242, generator=gen)) * (torch.rand(375, 1242, generator=gen) < 0.05)
+    a = np.array(ev.evaluate_image(disp.numpy(), gt.numpy())[0])
+    assert rel_err(torch.from_numpy(a), R.evaluate_image(disp, gt)) < 1e-5
+
+
+@pytest.mark.slow
+def test_val_absrel_oracle_matches_reference(golden, tmp_path):
+    """The oracle's eval-mode inference path + metric protocol reproduce the reference's unmodified `Trainer.val`
+    (trainer.py:653-857) on the synthetic eigen_zhou-format split: AbsRel and the other six errors, both networks."""
+    g = golden("eval")
+    ds, batch = _eval_split(tmp_path, g)
+    opt = types.SimpleNamespace(rep_size="b", g_blk=1.0, g_ffn=1.0, use_checkpoint=False, num_depth_bins=96)
+    from oracle import model_spec
+    sd = {k: synth.synth_tensor(k, torch.empty(shape, dtype=dt)) for k, (shape, dt) in model_spec.state_spec("b").items()}
+    model = RM.RefRepDepth(sd, opt)
+    model.training = False
+    disp, mono = model.predict_val(batch, torch.tensor([0.1]), torch.tensor([10.0]))
+    gts = ds.gt_depths()
+    err = torch.stack([R.evaluate_image(disp[i], torch.from_numpy(gts[i])) for i in range(len(gts))]).mean(0)
+    err_m = torch.stack([R.evaluate_image(mono[i], torch.from_numpy(gts[i])) for i in range(len(gts))]).mean(0)
+    assert abs(float(err[0]) - float(g["val_errors"][0])) < 1e-4            # AbsRel
+    assert abs(float(err_m[0]) - float(g["val_errors_mono"][0])) < 1e-4
+    assert rel_err(err, g["val_errors"]) < 1e-3 and rel_err(err_m, g["val_errors_mono"]) < 1e-3
