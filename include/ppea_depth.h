@@ -257,6 +257,44 @@ int ppea_loss_select_f32(const float* reproj, const float* identity, const float
                          int B, int C, int H, int W, int selec_reproj, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * A12 / A14  Dense convolutions as implicit GEMMs on the matrix cores (csrc/conv_nhwc.hip, conv_wgrad.hip):
+ *     bf16 channels-last activations, fp32 accumulation.  Replaces the library convolutions behind
+ *       ConvBlock / Conv3x3            layers.py:103-135 (decoder: networks/depth_decoder_v2.py:172-245)
+ *       ResNet-18 pose trunk          networks/resnet_encoder.py:25-72, 397-409
+ *       PoseDecoder                   networks/pose_decoder.py:33-52
+ *       reduce_conv                   networks/replk_matching_adapter.py:127-131
+ *       RepLKNet stem[0]              networks/replknet_adapter.py:411
+ *     forward and data gradient (one kernel: the data gradient runs it with the flipped / transposed operand image
+ *     and, for a strided forward, over the zero-dilated output gradient) and weight gradient.
+ *
+ *   ppea_conv_packed_bytes(Cout, Cin, R, S, flip)   bytes of the operand image of w [Cout][Cin][R][S]
+ *   ppea_conv_pack_weights(w, w_is_bf16, packed, Cout, Cin, R, S, flip)
+ *        flip = 0: [R*S][Cout][Cin padded to 32] (forward); flip = 1: [R*S reversed][Cin][Cout padded to 32] (dgrad)
+ *   ppea_conv_nhwc_bf16   y = act(bias + conv(x)):  x [N][H][W][Cin] (Cin % 8 == 0), y [N][Ho][Wo][Cout] or, with
+ *        out_nchw, [N][Cout][Ho][Wo]; R, S <= 7; stride 1 | 2; pad = zero padding, or reflect != 0: reflection
+ *        padding of `pad` <= 1 read through reflected indices (no padded copy); dil > 1: x is read as its zero-dilated
+ *        image (data gradient of a strided conv); bias fp32 or (bias_bf16) bf16 or NULL; act 0 none, 1 ReLU, 2 ELU,
+ *        3 sigmoid.
+ *   ppea_conv_wgrad_nhwc_bf16   dw [Cout][Cin][R][S] (fp32 or bf16) = sum_pixels dz (x) x, split over output patches
+ *        with fp32 partials in a caller-owned workspace of ppea_conv_wgrad_workspace_bytes(...) bytes
+ *        (deterministic; Cin % 8 == 0, Cout % 8 == 0).
+ *   ppea_image_to_nhwc_bf16   fp32 NCHW frames -> bf16 channels-last, channels zero-padded to Cp (% 8 == 0),
+ *        y = (x - sub) / div  (resnet_encoder.py:399 normalisation for the pose trunk; sub 0, div 1 for stem[0]).
+ * ---------------------------------------------------------------------------------------- */
+long ppea_conv_packed_bytes(int Cout, int Cin, int R, int S, int flip);
+int ppea_conv_pack_weights(const void* w, int w_is_bf16, void* packed, int Cout, int Cin, int R, int S, int flip,
+                           void* stream);
+int ppea_conv_nhwc_bf16(const void* x, const void* w_packed, const void* bias, int bias_bf16, void* y,
+                        int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int reflect, int dil,
+                        int Ho, int Wo, int act, int out_nchw, void* stream);
+long ppea_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int R, int S, int Ho, int Wo);
+int ppea_conv_wgrad_nhwc_bf16(const void* dz, const void* x, void* dw, int dw_bf16, void* workspace,
+                              int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int reflect,
+                              int Ho, int Wo, void* stream);
+int ppea_image_to_nhwc_bf16(const float* x, void* y, int N, int C, int H, int W, int Cp, float sub, float div,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * A9  match_features (replk_matching_adapter.py:261-340), one lookup frame per item.
  *      cur, lookup [B,C,h,w]; P [B,3,4] = (K @ T)[:, :3, :] at the matching scale;
  *      inv_K [B,4,4]; bins [D]; skip [B] int32 (non-zero = lookup pose was zeroed, item skipped

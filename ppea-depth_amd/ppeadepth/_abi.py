@@ -97,6 +97,12 @@ SIGNATURES = {
     "ppea_smooth_fwd_f32": [_vp] * 3 + [_i] * 4 + [_vp],
     "ppea_smooth_bwd_f32": [_vp, _vp, _f, _f, _vp] + [_i] * 4 + [_vp],
     "ppea_loss_select_f32": [_vp] * 9 + [_i] * 5 + [_vp],
+    "ppea_conv_packed_bytes": [_i] * 5,
+    "ppea_conv_pack_weights": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "ppea_image_to_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
+    "ppea_conv_nhwc_bf16": [_vp, _vp, _vp, _i, _vp] + [_i] * 15 + [_vp],
+    "ppea_conv_wgrad_workspace_bytes": [_i] * 7,
+    "ppea_conv_wgrad_nhwc_bf16": [_vp, _vp, _vp, _i, _vp] + [_i] * 12 + [_vp],
     "ppea_cost_volume_fwd_f32": [_vp] * 7 + [_i] * 5 + [_f, _vp],
     "ppea_cost_volume_reduce_f32": [_vp] * 6 + [_i] * 4 + [_vp],
 }

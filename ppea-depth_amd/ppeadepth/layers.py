@@ -75,10 +75,15 @@ class Conv3x3(nn.Module):
         self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
 
-    def forward(self, x):
+    def forward(self, x, act="none"):
         if self.use_refl and x.is_cuda:
-            return self.conv(ops.reflect_pad1(x))      # gather-style pad kernels (no atomics in backward)
-        return self.conv(self.pad(x))
+            y = ops.conv_module(self.conv, x, act, reflect=True)     # bf16 step: pad + conv + bias + act in one kernel
+            if y is not None:
+                return y
+            y = self.conv(ops.reflect_pad1(x))         # gather-style pad kernels (no atomics in backward)
+        else:
+            y = self.conv(self.pad(x))
+        return {"none": lambda t: t, "sigmoid": torch.sigmoid, "elu": F.elu}[act](y)
 
 
 class ConvBlock(nn.Module):
@@ -91,6 +96,10 @@ class ConvBlock(nn.Module):
 
     def forward(self, x):
         c = self.conv
+        if x.is_cuda and c.use_refl:
+            y = ops.conv_module(c.conv, x, "elu", reflect=True)
+            if y is not None:
+                return y
         if FUSE_BIAS_ELU and x.is_cuda and c.use_refl and c.conv.bias is not None:
             # conv without bias, then bias + ELU in one pass whose backward also yields the bias gradient
             z = F.conv2d(ops.reflect_pad1(x), c.conv.weight, None)

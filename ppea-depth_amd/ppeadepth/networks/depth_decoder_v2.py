@@ -80,5 +80,5 @@ class DepthDecoderV2(nn.Module):
         x = self.upconvs_1[-1](upsample(self.upconvs_0[-1](x)))
         if self.dc:
             x = x + F.interpolate(adpt_out, scale_factor=2)
-        self.outputs[("disp", 0)] = self.sigmoid(self.disp_convs[0](x))
+        self.outputs[("disp", 0)] = self.disp_convs[0](x, act="sigmoid")          # sigmoid in the conv's epilogue
         return self.outputs

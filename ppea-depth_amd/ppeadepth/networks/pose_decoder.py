@@ -21,12 +21,18 @@ class PoseDecoder(nn.Module):
         self.net = nn.ModuleList(list(self.convs.values()))
 
     def forward(self, input_features):
+        from .. import ops
         last = [f[-1] for f in input_features]
-        out = torch.cat([self.relu(self.convs["squeeze"](f)) for f in last], 1)
+
+        def conv(c, x, relu):                      # bias (+ ReLU) in the conv kernel's epilogue on the bf16 step
+            y = ops.conv_module(c, x, "relu" if relu else "none") if x.is_cuda else None
+            if y is None:
+                y = c(x)
+                y = self.relu(y) if relu else y
+            return y
+        out = torch.cat([conv(self.convs["squeeze"], f, True) for f in last], 1)
         for i in range(3):
-            out = self.convs[("pose", i)](out)
-            if i != 2:
-                out = self.relu(out)
+            out = conv(self.convs[("pose", i)], out, i != 2)
         out = out.mean(3).mean(2)
         out = 0.01 * out.view(-1, self.num_frames_to_predict_for, 1, 6)
         return out[..., :3], out[..., 3:]

@@ -99,7 +99,10 @@ class RepLKMatchingAdapter(nn.Module):
             cost_volume, confidence_mask, argmin, lowest_cost = ops.cost_volume_reduce(raw, self.depth_bins)
         self.argmin = argmin
         feat = self.features[-1]
-        x = self.reduce_conv(torch.cat([feat, cost_volume.to(feat.dtype)], 1))
+        cat = torch.cat([feat, cost_volume.to(feat.dtype)], 1)
+        x = ops.conv_module(self.reduce_conv[0], cat, "relu", out_nchw=True) if cat.is_cuda else None   # bias + ReLU fused
+        if x is None:
+            x = self.reduce_conv(cat)
         x = self.replk.transitions[0](x)
         for s in range(1, self.replk.num_stages):
             x = self.replk.stages[s](x)

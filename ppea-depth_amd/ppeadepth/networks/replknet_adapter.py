@@ -105,6 +105,15 @@ class SmallDW(nn.Conv2d):
         return super().forward(x)
 
 
+class ImageConv(nn.Conv2d):
+    """stem[0] (rka.py:411): dense 3x3 stride-2 conv on the RGB frame.  On the bf16 step: frame -> channels_last bf16
+    padded to 8 channels, then this build's implicit-GEMM kernel writing NCHW for the trunk."""
+
+    def forward(self, x):
+        y = ops.conv_module(self, x, out_nchw=True) if x.is_cuda else None
+        return super().forward(x) if y is None else y
+
+
 class PointwiseConv(nn.Conv2d):
     """1x1 stride-1 conv; frozen + bf16 activations run on the NCHW MFMA kernel (forward with W, data
     gradient with W^T), everything else on the library conv."""
@@ -131,6 +140,8 @@ def get_conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation
     if (in_channels == out_channels == groups and k > 5 and stride == 1 and padding == k // 2
             and dilation == 1):
         return LargeKernelDW(in_channels, k, bias=bias)
+    if groups == 1 and k == 3 and in_channels < 8 and dilation == 1:
+        return ImageConv(in_channels, out_channels, 3, stride, padding, dilation, 1, bias)
     return nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
 
 

@@ -65,6 +65,13 @@ class GroupBN(nn.BatchNorm2d):
         self.num_batches_tracked += 1
 
 
+def _conv(c, x):
+    """nn.Conv2d of the pose trunk: this build's implicit-GEMM kernels on the bf16 step, the library otherwise."""
+    from .. import ops
+    y = ops.conv_module(c, x) if x.is_cuda else None
+    return c(x) if y is None else y
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -80,9 +87,9 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         if FUSED_NHWC_BN and self.training and x.is_cuda:
-            identity = x if self.downsample is None else self.downsample[1].fused(self.downsample[0](x))
-            out = self.bn1.fused(self.conv1(x), 1)
-            return self.bn2.fused(self.conv2(out), 1, identity)
+            identity = x if self.downsample is None else self.downsample[1].fused(_conv(self.downsample[0], x))
+            out = self.bn1.fused(_conv(self.conv1, x), 1)
+            return self.bn2.fused(_conv(self.conv2, out), 1, identity)
         identity = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
@@ -184,6 +191,17 @@ class ResnetEncoder(nn.Module):
 
     def _forward(self, input_image):
         e = self.encoder
+        from .. import ops
+        if (ops.CONV_MFMA and input_image.is_cuda and input_image.dtype == torch.float32 and ops.bf16_autocast()
+                and FUSED_NHWC_BN and self.training):
+            # normalisation, bf16 rounding (what autocast feeds conv1), 6 -> 8 channels and channels_last in one kernel
+            x = ops.image_to_nhwc(input_image, 8, 0.45, 0.225)
+            self.features = [e.bn1.fused(_conv(e.conv1, x), 1)]
+            self.features.append(e.layer1(e.maxpool(self.features[-1])))
+            self.features.append(e.layer2(self.features[-1]))
+            self.features.append(e.layer3(self.features[-1]))
+            self.features.append(e.layer4(self.features[-1]))
+            return self.features
         x = (input_image - 0.45) / 0.225
         if CHANNELS_LAST and x.is_cuda:
             # MIOpen's implicit-GEMM convolutions are NHWC-native: with a channels_last input every activation of the

@@ -905,3 +905,169 @@ def mlp_adapter(x, w1, b1, w2, b2):
 
 def conv_adapter(x, w1, b1, w2, b2):
     return _ConvAdapterFn.apply(x, w1, b1, w2, b2)
+
+
+# ---------------------------------------------------------------------------------------------
+# A12 / A14  dense convolutions as implicit GEMMs on the matrix cores (csrc/conv_nhwc.hip, conv_wgrad.hip):
+# decoder ConvBlock / Conv3x3 (layers.py:103-135), pose ResNet-18 + PoseDecoder, reduce_conv, stem[0]
+# ---------------------------------------------------------------------------------------------
+CONV_ACT = {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3}
+CONV_MFMA = True       # dense convs of the bf16 step on this build's implicit-GEMM kernels (False: library convs)
+
+
+def bf16_autocast():
+    return torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == _BF16
+
+
+def conv_module(conv, x, act="none", reflect=False, out_nchw=False):
+    """nn.Conv2d `conv` applied through the implicit-GEMM kernels when the bf16 step is running (x bf16, or an fp32
+    image under bf16 autocast for the image-fed layers); None when this call is not served (caller uses the library)."""
+    if not (CONV_MFMA and x.is_cuda and conv.groups == 1 and conv.dilation[0] == 1 and conv.stride[0] in (1, 2)
+            and conv.kernel_size[0] == conv.kernel_size[1] and conv.kernel_size[0] <= 7):
+        return None
+    if x.dtype == _F32 and x.shape[1] < 8 and bf16_autocast():
+        x = image_to_nhwc(x, 8)
+    if x.dtype != _BF16 or x.shape[1] % 8 != 0:
+        return None
+    return conv2d_nhwc(x, conv.weight, conv.bias, conv.stride[0], 1 if reflect else conv.padding[0], reflect, act, out_nchw)
+_CONV_PACK_CACHE = {}
+
+
+def _conv_packed(w, flip):
+    """bf16 operand image of w [Cout,Cin,R,S] (flip: the data-gradient operand).  Frozen weights are packed once per
+    version; trainable ones on every use (the flat Adam kernel updates them through raw pointers)."""
+    Cout, Cin, R, S = w.shape
+    cacheable = not w.requires_grad
+    key = (id(w), int(flip))
+    hit = _CONV_PACK_CACHE.get(key) if cacheable else None
+    if hit is not None and hit[2]() is w and hit[0] == w._version:
+        return hit[1]
+    wd = w.detach()
+    if wd.dtype not in (_F32, _BF16) or not wd.is_contiguous():
+        wd = wd.float().contiguous()
+    buf = torch.empty(_abi.lib.ppea_conv_packed_bytes(Cout, Cin, R, S, int(flip)) // 2, dtype=_BF16, device=w.device)
+    call("ppea_conv_pack_weights", ptr(wd), int(wd.dtype == _BF16), ptr(buf), Cout, Cin, R, S, int(flip), stream_ptr())
+    if cacheable:
+        _CONV_PACK_CACHE[key] = (w._version, buf, weakref.ref(w, lambda _r, k=key: _CONV_PACK_CACHE.pop(k, None)))
+    return buf
+
+
+def _nhwc_raw(t):
+    """Pointer of a channels_last (or C == 1 / 1x1 degenerate) 4-D tensor's storage."""
+    return _ct.c_void_p(t.data_ptr())
+
+
+def _as_nhwc(t):
+    return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+
+def conv_nhwc_raw(x, wp, bias, Cout, R, S, stride, pad, reflect, dil, Ho, Wo, act, out_nchw):
+    """One launch of the implicit-GEMM kernel.  x: bf16, channels_last storage, logical [N,Cin,H,W]."""
+    N, Cin, H, W = x.shape
+    if out_nchw:
+        y = torch.empty(N, Cout, Ho, Wo, device=x.device, dtype=_BF16)
+    else:
+        y = torch.empty(N, Cout, Ho, Wo, device=x.device, dtype=_BF16, memory_format=torch.channels_last)
+    bp, bflag = _bias_arg(bias)
+    call("ppea_conv_nhwc_bf16", _nhwc_raw(x), ptr(wp), bp, bflag, _nhwc_raw(y), N, H, W, Cin, Cout, R, S, stride, pad,
+         int(reflect), dil, Ho, Wo, act, int(out_nchw), stream_ptr())
+    return y
+
+
+def conv_supported(x, w):
+    return (x.is_cuda and x.dtype == _BF16 and x.dim() == 4 and x.shape[1] % 8 == 0 and w.shape[2] <= 7
+            and w.shape[3] <= 7)
+
+
+class _ConvNhwc(torch.autograd.Function):
+    """y = act(conv2d(x, w, stride, pad | reflection pad) + bias) -- forward, data gradient and weight gradient on the
+    implicit-GEMM kernels; bias gradient and the activation's derivative in one pass before them."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, reflect, act, out_nchw):
+        x = _as_nhwc(x)
+        N, Cin, H, W = x.shape
+        Cout, _, R, S = w.shape
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        y = conv_nhwc_raw(x, _conv_packed(w, False), None if bias is None else bias.detach().contiguous(), Cout, R, S, stride,
+                          pad, reflect, 1, Ho, Wo, act, out_nchw)
+        ctx.save_for_backward(x, w, y if act != 0 else None)
+        ctx.cfg = (stride, pad, bool(reflect), act, bool(out_nchw), bias is not None,
+                   None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, reflect, act, out_nchw, has_bias, bdt = ctx.cfg
+        N, Cin, H, W = x.shape
+        Cout, _, R, S = w.shape
+        Ho, Wo = dy.shape[2], dy.shape[3]
+        db = None
+        # ---- dz = dy * act'(y), channels_last bf16; bias gradient ------------------------------------------------------
+        if act == 2 and not out_nchw and _nhwc_c_ok(Cout):
+            dy = dy.contiguous(memory_format=torch.channels_last).to(_BF16)
+            slabs = _abi.lib.ppea_nhwc_bias_elu_slabs(N * Ho * Wo, Cout)
+            partial = torch.empty(slabs, Cout, device=dy.device, dtype=_F32)
+            dz = torch.empty_like(dy)
+            call("ppea_nhwc_bias_elu_bwd_bf16", _raw(dy), _raw(y), _raw(dz), ptr(partial), N * Ho * Wo, Cout, stream_ptr())
+            if has_bias and ctx.needs_input_grad[2]:
+                db = partial.sum(0).to(bdt)
+        else:
+            if act == 1:
+                dz = dy * (y > 0)
+            elif act == 2:
+                dz = dy * torch.where(y > 0, torch.ones_like(y), y + 1)
+            elif act == 3:
+                dz = dy * (y * (1 - y))
+            else:
+                dz = dy
+            if has_bias and ctx.needs_input_grad[2]:
+                db = dz.float().sum((0, 2, 3)).to(bdt)
+            dz = _as_nhwc(dz.to(_BF16))
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = _conv_packed(w, True)                           # [R*S flipped][Cin][Cout padded to 32]
+            if reflect:
+                # gradient on the reflection-padded domain, then folded back (layers.py:119-135)
+                dpad = conv_nhwc_raw(dz, wt, None, Cin, R, S, 1, R - 1, False, stride, Ho + R - 1, Wo + S - 1, 0, False)
+                dx = torch.empty(N, Cin, H, W, device=dz.device, dtype=_BF16, memory_format=torch.channels_last)
+                call("ppea_nhwc_reflect_pad1_bwd_bf16", _raw(dpad), _raw(dx), N, H, W, Cin, stream_ptr())
+            else:
+                dx = conv_nhwc_raw(dz, wt, None, Cin, R, S, 1, R - 1 - pad, False, stride, H, W, 0, False)
+        if ctx.needs_input_grad[1]:
+            if Cout % 8 != 0:
+                raise _abi.PpeaKernelError("conv weight gradient: output channels must be a multiple of 8 "
+                                           "(pad the layer, see conv2d_nhwc)")
+            ws = torch.empty(_abi.lib.ppea_conv_wgrad_workspace_bytes(N, Cin, Cout, R, S, Ho, Wo) // 4, device=dz.device,
+                             dtype=_F32)
+            gdt = w.dtype if w.dtype in (_BF16, _F32) else _F32
+            dw = torch.empty(Cout, Cin, R, S, device=dz.device, dtype=gdt)
+            call("ppea_conv_wgrad_nhwc_bf16", _raw(dz), _raw(x), ptr(dw), int(gdt == _BF16), ptr(ws), N, H, W, Cin, Cout, R, S,
+                 stride, pad, int(reflect), Ho, Wo, stream_ptr())
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv2d_nhwc(x, w, bias=None, stride=1, pad=0, reflect=False, act="none", out_nchw=False):
+    """Dense conv on the matrix cores.  x [N,Cin,H,W] bf16 (channels_last storage preferred), w [Cout,Cin,R,S] (bf16 or
+    fp32 parameter), -> [N,Cout,Ho,Wo] bf16 channels_last (or NCHW-contiguous with out_nchw).  Layers whose output
+    channel count is not a multiple of 8 (disp conv: 1, pose head: 12) run zero-padded to the next multiple."""
+    Cout = w.shape[0]
+    if w.shape[1] < x.shape[1]:                 # image-fed layers: x was zero-padded to 8 channels (image_to_nhwc)
+        w = torch.cat([w, w.new_zeros(Cout, x.shape[1] - w.shape[1], *w.shape[2:])], 1)
+    if Cout % 8 != 0:
+        padn = 8 - Cout % 8
+        w8 = torch.cat([w, w.new_zeros(padn, *w.shape[1:])], 0)
+        b8 = None if bias is None else torch.cat([bias, bias.new_zeros(padn)], 0)
+        y = _ConvNhwc.apply(x, w8, b8, stride, pad, reflect, CONV_ACT[act], out_nchw)
+        return y[:, :Cout]
+    return _ConvNhwc.apply(x, w, bias, stride, pad, reflect, CONV_ACT[act], out_nchw)
+
+
+def image_to_nhwc(x, cp=8, sub=0.0, div=1.0):
+    """fp32 NCHW image(s) -> bf16 channels_last with the channels zero-padded to `cp`; y = (x - sub) / div."""
+    x = x.contiguous().float()
+    N, C, H, W = x.shape
+    y = torch.empty(N, cp, H, W, device=x.device, dtype=_BF16, memory_format=torch.channels_last)
+    call("ppea_image_to_nhwc_bf16", ptr(x), _nhwc_raw(y), N, C, H, W, cp, float(sub), float(div), stream_ptr())
+    return y

@@ -729,3 +729,82 @@ def test_structural_reparam_and_deep_fuse_bn_equivalence(device):
         fused = net(x)
         for a, b in zip(fused, base):
             assert rel_err(a, b) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# A12 / A14: dense convolutions on the implicit-GEMM MFMA kernels (conv_nhwc.hip / conv_wgrad.hip)
+# ---------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # name,            N, Cin, H,  W,  Cout, k, stride, pad, reflect, act,       bias,  nchw
+    ("dec_32_32",      2, 32,  24, 40, 32,   3, 1,      1,   True,    "elu",     True,  False),
+    ("dec_64_32_odd",  1, 64,  13, 21, 32,   3, 1,      1,   True,    "elu",     True,  False),
+    ("dec_1024_512",   2, 1024, 6, 20, 512,  3, 1,      1,   True,    "elu",     True,  False),
+    ("dec_256_128",    2, 256, 24, 16, 128,  3, 1,      1,   True,    "elu",     True,  False),
+    ("disp_32_1",      2, 32,  16, 24, 1,    3, 1,      1,   True,    "sigmoid", True,  False),
+    ("reduce_224_128", 2, 224, 12, 40, 128,  3, 1,      1,   False,   "relu",    True,  True),
+    ("res_64_64",      3, 64,  12, 20, 64,   3, 1,      1,   False,   "none",    False, False),
+    ("res_64_128_s2",  3, 64,  12, 20, 128,  3, 2,      1,   False,   "none",    False, False),
+    ("res_64_128_s2o", 2, 64,  13, 19, 128,  3, 2,      1,   False,   "none",    False, False),
+    ("down_64_128_s2", 3, 64,  12, 20, 128,  1, 2,      0,   False,   "none",    False, False),
+    ("conv1_7x7_s2",   2, 8,   32, 48, 64,   7, 2,      3,   False,   "none",    False, False),
+    ("stem_3x3_s2",    2, 8,   32, 48, 128,  3, 2,      1,   False,   "none",    False, True),
+    ("squeeze_1x1",    4, 512, 6,  20, 256,  1, 1,      0,   False,   "relu",    True,  False),
+    ("posehead_12",    4, 256, 6,  20, 12,   1, 1,      0,   False,   "none",    True,  False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_nhwc_mfma(device, case):
+    """Forward, data gradient, weight gradient and bias gradient of the implicit-GEMM convolution kernels against a
+    plain fp32 PyTorch reference of the same op on the same bf16-rounded operands (reflection / zero padding, stride
+    1 / 2, 1x1 / 3x3 / 7x7, fused bias + ReLU / ELU / sigmoid, channels_last and NCHW outputs, ragged sizes).
+    Tolerance: fp32 accumulation on both sides, ONE bf16 rounding of every output element -> 2^-7 of the tensor's max."""
+    import torch.nn.functional as F
+    from ppeadepth import ops
+    name, N, Cin, H, W, Cout, k, stride, pad, reflect, act, has_bias, nchw = case
+    g = _g(len(name) * 7 + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g).bfloat16()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).bfloat16()
+    b = (0.2 * torch.randn(Cout, generator=g)).bfloat16() if has_bias else None
+
+    def ref(xr, wr, br):
+        xp = F.pad(xr, (pad,) * 4, mode="reflect") if reflect else xr
+        z = F.conv2d(xp, wr, br, stride, 0 if reflect else pad)
+        return {"none": z, "relu": F.relu(z), "elu": F.elu(z), "sigmoid": torch.sigmoid(z)}[act]
+    leaves = [t.float().clone().requires_grad_(True) if t is not None else None for t in (x, w, b)]
+    yr = ref(*leaves)
+    go = torch.randn(yr.shape, generator=g).bfloat16()
+    yr.backward(go.float())
+
+    xd = x.to(device).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to(device).requires_grad_(True)
+    bd = b.to(device).requires_grad_(True) if has_bias else None
+    assert ops.conv_supported(xd, wd)
+    y = ops.conv2d_nhwc(xd, wd, bd, stride, pad, reflect, act, nchw)
+    assert y.shape == yr.shape and y.dtype == torch.bfloat16
+    assert y.is_contiguous() if nchw else (Cout % 8 != 0 or y.is_contiguous(memory_format=torch.channels_last))
+    y.backward(go.to(device))
+    tol = 2 ** -7
+    assert rel_err(y.float().cpu(), yr.detach()) < tol
+    if Cin != 8:                                    # the image-fed layers (stem, pose conv1) need no data gradient
+        assert rel_err(xd.grad.float().cpu(), leaves[0].grad) < tol
+    assert rel_err(wd.grad.float().cpu(), leaves[1].grad) < tol
+    if has_bias:
+        assert rel_err(bd.grad.float().cpu(), leaves[2].grad) < tol
+
+
+def test_image_to_nhwc_and_conv_full_size(device):
+    """The two image-fed layers at full size: the fp32 NCHW frames are normalised, padded to 8 channels and laid out
+    channels_last by one kernel (resnet_encoder.py:399 `(x - 0.45) / 0.225`), then convolved."""
+    import torch.nn.functional as F
+    from ppeadepth import ops
+    g = _g(5)
+    img = torch.rand(2, 6, 192, 640, generator=g)
+    w = (torch.randn(64, 6, 7, 7, generator=g) / 17).bfloat16()
+    xn = ops.image_to_nhwc(img.to(device), 8, 0.45, 0.225)
+    want = ((img - 0.45) / 0.225).bfloat16()
+    assert torch.equal(xn[:, :6].cpu().float(), want.float()) and float(xn[:, 6:].abs().max()) == 0.0
+    w8 = torch.cat([w, torch.zeros(64, 2, 7, 7, dtype=torch.bfloat16)], 1).to(device)
+    y = ops.conv2d_nhwc(xn, w8, None, 2, 3)
+    yr = F.conv2d(want.float(), w.float(), None, 2, 3)
+    assert rel_err(y.float().cpu(), yr) < 2 ** -7
