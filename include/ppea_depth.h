@@ -287,7 +287,7 @@ int ppea_conv_pack_weights(const void* w, int w_is_bf16, void* packed, int Cout,
 int ppea_conv_nhwc_bf16(const void* x, const void* w_packed, const void* bias, int bias_bf16, void* y,
                         int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int reflect, int dil,
                         int Ho, int Wo, int act, int out_nchw, void* stream);
-long ppea_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int R, int S, int Ho, int Wo);
+long ppea_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int R, int S, int stride, int Ho, int Wo);
 int ppea_conv_wgrad_nhwc_bf16(const void* dz, const void* x, void* dw, int dw_bf16, void* workspace,
                               int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int reflect,
                               int Ho, int Wo, void* stream);

@@ -30,11 +30,13 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int TH = 8, TW = 16;        // output patch of a workgroup
+constexpr int TILE_PX = 128;          // output pixels of a workgroup: TR rows x TC columns, TR * TC <= 128
 constexpr int PITCH = 80;             // bytes per pixel / weight row in LDS (32 channels + 16 B)
-// staging registers per thread: 16-byte halo chunks / weight chunks for the largest filter an instantiation serves
-constexpr int max_a(int stride, int kmax) { return (((TH - 1) * stride + kmax) * ((TW - 1) * stride + kmax) * 4 + 255) / 256; }
-constexpr int max_b(int bn, int kmax) { return (kmax * bn * 4 + 255) / 256; }
+// largest halo (pixels) an instantiation stages: stride 1, 3x3: (2,64) -> 4 x 66; stride 2, 3x3: (4,32) -> 9 x 65;
+// 7x7: (8,16) -> 14 x 22 (stride 1, the dilated data gradient) / 21 x 37 (stride 2)
+constexpr int halo_cap(int stride, int ks) {
+    return ks <= 3 ? (stride == 1 ? 4 * 66 : 9 * 65) : (stride == 1 ? 14 * 22 : 21 * 37);
+}
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
 __device__ __forceinline__ uint16_t f2bf(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
@@ -44,29 +46,26 @@ struct ConvArgs {
     const uint16_t* w;      // packed [R*S][Cout][CinP], CinP = Cin rounded up to 32, zero filled
     const void* bias;       // [Cout] fp32 / bf16 or null
     uint16_t* y;            // [N][Ho][Wo][Cout] or [N][Cout][Ho][Wo]
-    int N, H, W, Cin, CinP, Cout, R, S, stride, pad, reflect, dil, Ho, Wo, act, bias_bf16;
-    int tiles_x, tiles_y;
+    int N, H, W, Cin, CinP, Cout, stride, pad, reflect, dil, Ho, Wo, act, bias_bf16;
+    int TR, TC, tiles_x, tiles_y;
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
 
-// BN output channels per workgroup; WM x WN waves; STRIDE compile time (halo geometry); NCHW output flag.
-template <int BN, int WM, int WN, int STRIDE, bool OUT_NCHW, int KMAX>
-__global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs a) {
+// BN output channels per workgroup; WM x WN waves; STRIDE and the (square) filter size KS compile time.
+template <int BN, int WM, int WN, int STRIDE, bool OUT_NCHW, int KS>
+__global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "four waves");
-    constexpr int MAX_A = max_a(STRIDE, KMAX), MAX_B = max_b(BN, KMAX);
-    constexpr int MT = TH / WM;            // 16-pixel rows per wave
+    constexpr int MAX_A = (halo_cap(STRIDE, KS) * 4 + 255) / 256, MAX_B = (KS * BN * 4 + 255) / 256;
+    constexpr int MT = 8 / WM;             // 16-pixel M tiles per wave
     constexpr int NT = BN / 16 / WN;       // 16-channel column tiles per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
-    const int R = a.R, S = a.S;
-    const int HALO_H = (TH - 1) * STRIDE + R, HALO_W = (TW - 1) * STRIDE + S;
+    const int TR = a.TR, TC = a.TC;
+    const int HALO_H = (TR - 1) * STRIDE + KS, HALO_W = (TC - 1) * STRIDE + KS;
     const int halo_px = HALO_H * HALO_W;
-    const int A_BYTES = ((halo_px * PITCH + 127) / 128) * 128;
-    const int B_BYTES = S * BN * PITCH;
-    const int n_abuf = a.CinP > 32 ? 2 : 1;        // a single channel slice never re-stages the halo
-    uint8_t* ldsA[2] = {lds, lds + (n_abuf - 1) * A_BYTES};
-    uint8_t* ldsB[2] = {lds + n_abuf * A_BYTES, lds + n_abuf * A_BYTES + B_BYTES};
+    uint8_t* ldsA = lds;
+    uint8_t* ldsB = lds + ((halo_px * PITCH + 127) / 128) * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -76,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs a) {
     const int tx = t % a.tiles_x; t /= a.tiles_x;
     const int ty = t % a.tiles_y;
     const int n = t / a.tiles_y;
-    const int oh0 = ty * TH, ow0 = tx * TW;
+    const int oh0 = ty * TR, ow0 = tx * TC;
     const int ih0 = oh0 * STRIDE - a.pad, iw0 = ow0 * STRIDE - a.pad;
     const int Hl = (a.H - 1) * a.dil + 1, Wl = (a.W - 1) * a.dil + 1;      // logical (zero-dilated) input size
     const uint16_t* xn = a.x + (long)n * a.H * a.W * a.Cin;
@@ -90,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs a) {
     // ---- staging plans -------------------------------------------------------------------------------------------
     // halo: chunk q = pixel * 4 + c16; its source offset (in elements, -1 = zero) does not depend on the channel slice
     const int a_chunks = halo_px * 4;
-    long a_src[MAX_A];
+    int a_src[MAX_A];
 #pragma unroll
     for (int c = 0; c < MAX_A; ++c) {
         const int q = tid + c * 256;
@@ -105,10 +104,10 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs a) {
                 iw = iw < 0 ? 0 : (iw >= Wl ? Wl - 1 : iw);
             }
             const bool ok = ih >= 0 && ih < Hl && iw >= 0 && iw < Wl && (ih % a.dil) == 0 && (iw % a.dil) == 0;
-            if (ok) a_src[c] = ((long)(ih / a.dil) * a.W + iw / a.dil) * a.Cin + (q & 3) * 8;
+            if (ok) a_src[c] = ((ih / a.dil) * a.W + iw / a.dil) * a.Cin + (q & 3) * 8;      // < 2^31 per image
         }
     }
-    const int b_chunks = S * BN * 4;
+    constexpr int b_chunks = KS * BN * 4;
     uint4 a_reg[MAX_A], b_reg[MAX_B];
 
     auto load_a = [&](int c0) {
@@ -122,11 +121,11 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs a) {
             }
         }
     };
-    auto store_a = [&](uint8_t* dst) {
+    auto store_a = [&]() {
 #pragma unroll
         for (int c = 0; c < MAX_A; ++c) {
             const int q = tid + c * 256;
-            if (q < a_chunks) *reinterpret_cast<uint4*>(dst + (q >> 2) * PITCH + (q & 3) * 16) = a_reg[c];
+            if (q < a_chunks) *reinterpret_cast<uint4*>(ldsA + (q >> 2) * PITCH + (q & 3) * 16) = a_reg[c];
         }
     };
     auto load_b = [&](int c0, int r) {
@@ -137,48 +136,54 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs a) {
                 const int row = q >> 2;                       // s * BN + column
                 const int s = row / BN, co = co0 + row % BN;
                 b_reg[c] = co < a.Cout ? *reinterpret_cast<const uint4*>(
-                                             a.w + ((long)(r * S + s) * a.Cout + co) * a.CinP + c0 + (q & 3) * 8)
+                                             a.w + ((long)(r * KS + s) * a.Cout + co) * a.CinP + c0 + (q & 3) * 8)
                                        : make_uint4(0, 0, 0, 0);
             }
         }
     };
-    auto store_b = [&](uint8_t* dst) {
+    auto store_b = [&]() {
 #pragma unroll
         for (int c = 0; c < MAX_B; ++c) {
             const int q = tid + c * 256;
-            if (q < b_chunks) *reinterpret_cast<uint4*>(dst + (q >> 2) * PITCH + (q & 3) * 16) = b_reg[c];
+            if (q < b_chunks) *reinterpret_cast<uint4*>(ldsB + (q >> 2) * PITCH + (q & 3) * 16) = b_reg[c];
         }
     };
 
-    // ---- main loop over (channel slice, filter row) ------------------------------------------------------------------
-    const int n_slices = a.CinP / 32, steps = n_slices * R;
+    // per-lane fragment bases: M tile i of this wave covers linear tile pixels m = (wm*MT + i)*16 + li -> (m / TC, m % TC)
+    int a_off[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = (wm * MT + i) * 16 + li;
+        if (m >= TR * TC) m = 0;                               // padding rows of the tile: any valid address
+        a_off[i] = ((m / TC) * STRIDE * HALO_W + (m % TC) * STRIDE) * PITCH + g * 16;
+    }
+    const int b_off = (wn * NT * 16 + li) * PITCH + g * 16;
+
+    // ---- main loop over (channel slice, filter row): registers hold the NEXT step's operands while this one computes ----
+    const int steps = (a.CinP / 32) * KS;
     load_a(0);
     load_b(0, 0);
-    store_a(ldsA[0]);
-    store_b(ldsB[0]);
-    __syncthreads();
-    int pa = 0;
     for (int st = 0; st < steps; ++st) {
-        const int r = st % R;
+        const int r = st % KS;
+        __syncthreads();                                       // every wave is done with the previous step's LDS image
+        store_b();
+        if (r == 0) store_a();
+        __syncthreads();
         const int nxt = st + 1;
-        const bool more = nxt < steps;
-        const bool new_slice = more && (nxt % R) == 0;
-        if (more) {
-            load_b((nxt / R) * 32, nxt % R);
-            if (new_slice) load_a((nxt / R) * 32);
+        if (nxt < steps) {
+            load_b((nxt / KS) * 32, nxt % KS);
+            if ((nxt % KS) == 0) load_a((nxt / KS) * 32);
         }
-        const uint8_t* As = ldsA[pa];
-        const uint8_t* Bs = ldsB[st & 1];
-        const uint8_t* a_base = As + ((wm * MT * STRIDE + r) * HALO_W + li * STRIDE) * PITCH + g * 16;
-        const uint8_t* b_base = Bs + (wn * NT * 16 + li) * PITCH + g * 16;
-        for (int s = 0; s < S; ++s) {
+        const uint8_t* a_row = ldsA + r * HALO_W * PITCH;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
             bf16x8 af[MT], bfr[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_base + (i * STRIDE * HALO_W + s) * PITCH));
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a_row + a_off[i] + s * PITCH));
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b_base + (s * BN + j * 16) * PITCH));
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ldsB + b_off + (s * BN + j * 16) * PITCH));
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -189,12 +194,6 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
                 }
         }
-        if (more) {
-            store_b(ldsB[(st + 1) & 1]);
-            if (new_slice) store_a(ldsA[pa ^ 1]);
-        }
-        __syncthreads();
-        if (new_slice) pa ^= 1;
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
@@ -212,15 +211,14 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs a) {
     };
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int oh = oh0 + wm * MT + i;
-        if (oh >= a.Ho) continue;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int cb = co0 + (wn * NT + j) * 16;
             if constexpr (OUT_NCHW) {
-                // C: column = li = channel, row = 4 g + e = pixel ow0 + 4 g + e
-                const int co = cb + li, ow = ow0 + 4 * g;
-                if (co >= a.Cout || ow >= a.Wo) continue;
+                // C: column = li = channel, row = 4 g + e = tile pixel m0 + e (TC % 4 == 0: one output row, 4 columns)
+                const int m0 = (wm * MT + i) * 16 + 4 * g;
+                const int oh = oh0 + m0 / TC, ow = ow0 + m0 % TC, co = cb + li;
+                if (m0 >= TR * TC || oh >= a.Ho || co >= a.Cout || ow >= a.Wo) continue;
                 const float bv = bias_at(co);
                 uint16_t* dst = a.y + (((long)n * a.Cout + co) * a.Ho + oh) * a.Wo + ow;
                 uint16_t v[4];
@@ -234,9 +232,10 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs a) {
                         if (ow + e < a.Wo) dst[e] = v[e];
                 }
             } else {
-                // C: column = li = pixel ow0 + li, row = 4 g + e = channel cb + 4 g + e
-                const int ow = ow0 + li, co = cb + 4 * g;
-                if (ow >= a.Wo || co >= a.Cout) continue;
+                // C: column = li = tile pixel, row = 4 g + e = channel cb + 4 g + e
+                const int m = (wm * MT + i) * 16 + li;
+                const int oh = oh0 + m / TC, ow = ow0 + m % TC, co = cb + 4 * g;
+                if (m >= TR * TC || oh >= a.Ho || ow >= a.Wo || co >= a.Cout) continue;
                 uint16_t* dst = a.y + (((long)n * a.Ho + oh) * a.Wo + ow) * a.Cout + co;
                 uint16_t v[4];
 #pragma unroll
@@ -253,13 +252,31 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(const ConvArgs a) {
     }
 }
 
-template <int BN, int WM, int WN, int STRIDE, bool NCHW, int KMAX>
+// tile shape: TR rows x TC columns (TR * TC <= 128) covering the output with the least padding; NCHW stores want TC % 4 == 0
+void pick_tile(ConvArgs& a, int stride, int ks, bool nchw) {
+    int best_tr = 8, best_tc = 16;
+    long best = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
+    const int cand[4][2] = {{4, 32}, {2, 64}, {a.Wo <= 64 ? TILE_PX / a.Wo : 0, a.Wo}, {0, 0}};
+    for (int c = 0; c < 3; ++c) {
+        int tr = cand[c][0], tc = cand[c][1];
+        if (tr <= 0 || tc <= 0) continue;
+        if (tr > a.Ho) tr = a.Ho;
+        if (nchw && (tc & 3)) continue;
+        if (((tr - 1) * stride + ks) * ((tc - 1) * stride + ks) > halo_cap(stride, ks)) continue;
+        const long tiles = (long)((a.Ho + tr - 1) / tr) * ((a.Wo + tc - 1) / tc);
+        if (tiles < best) { best = tiles; best_tr = tr; best_tc = tc; }
+    }
+    a.TR = best_tr; a.TC = best_tc;
+    a.tiles_x = (a.Wo + a.TC - 1) / a.TC; a.tiles_y = (a.Ho + a.TR - 1) / a.TR;
+}
+
+template <int BN, int WM, int WN, int STRIDE, bool NCHW, int KS>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
-    const int halo_px = ((TH - 1) * STRIDE + a.R) * ((TW - 1) * STRIDE + a.S);
-    const int A_BYTES = ((halo_px * PITCH + 127) / 128) * 128, B_BYTES = a.S * BN * PITCH;
-    const size_t smem = (a.CinP > 32 ? 2 : 1) * (size_t)A_BYTES + 2 * (size_t)B_BYTES;
+    const int halo_px = ((a.TR - 1) * STRIDE + KS) * ((a.TC - 1) * STRIDE + KS);
+    if (halo_px > halo_cap(STRIDE, KS)) return PPEA_ERR_UNSUPPORTED;
+    const size_t smem = (size_t)((halo_px * PITCH + 127) / 128) * 128 + (size_t)KS * BN * PITCH;
     if (smem > 160 * 1024) return PPEA_ERR_UNSUPPORTED;
-    auto kern = conv_nhwc_kernel<BN, WM, WN, STRIDE, NCHW, KMAX>;
+    auto kern = conv_nhwc_kernel<BN, WM, WN, STRIDE, NCHW, KS>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
@@ -269,16 +286,26 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     return launch_status();
 }
 
-template <int STRIDE, bool NCHW>
-int dispatch_conv(const ConvArgs& a, hipStream_t st) {
+template <int STRIDE, bool NCHW, int KS>
+int dispatch_bn(const ConvArgs& a, hipStream_t st) {
     const long tiles = (long)a.tiles_x * a.tiles_y * a.N;
-    if (a.R > 3 || a.S > 3) {                         // 7x7 (pose conv1) / 5x5: one wide-halo instantiation
-        if (a.Cout > 32) return launch_conv<64, 2, 2, STRIDE, NCHW, 7>(a, st);
-        return launch_conv<32, 4, 1, STRIDE, NCHW, 7>(a, st);
+    if constexpr (KS <= 3) {
+        // 128 channels per workgroup only when that still leaves two waves of workgroups for the 256 CUs
+        if (a.Cout > 64 && tiles * ((a.Cout + 127) / 128) >= 512) return launch_conv<128, 2, 2, STRIDE, NCHW, KS>(a, st);
     }
-    if (a.Cout > 64 && tiles * ((a.Cout + 127) / 128) >= 256) return launch_conv<128, 2, 2, STRIDE, NCHW, 3>(a, st);
-    if (a.Cout > 32) return launch_conv<64, 2, 2, STRIDE, NCHW, 3>(a, st);
-    return launch_conv<32, 4, 1, STRIDE, NCHW, 3>(a, st);
+    if (a.Cout > 32) return launch_conv<64, 2, 2, STRIDE, NCHW, KS>(a, st);
+    return launch_conv<32, 4, 1, STRIDE, NCHW, KS>(a, st);
+}
+
+template <int STRIDE, bool NCHW>
+int dispatch_conv(ConvArgs& a, int ks, hipStream_t st) {
+    pick_tile(a, STRIDE, ks, NCHW);
+    switch (ks) {
+        case 1: return dispatch_bn<STRIDE, NCHW, 1>(a, st);
+        case 3: return dispatch_bn<STRIDE, NCHW, 3>(a, st);
+        case 7: return dispatch_bn<STRIDE, NCHW, 7>(a, st);
+    }
+    return PPEA_ERR_UNSUPPORTED;
 }
 
 // weights [Cout][Cin][R][S] (bf16 or fp32) -> packed bf16 [R*S][Cout][CinP]  (flip = 0)
@@ -357,18 +384,18 @@ int ppea_conv_nhwc_bf16(const void* x, const void* w_packed, const void* bias, i
                         int Cin, int Cout, int R, int S, int stride, int pad, int reflect, int dil, int Ho, int Wo, int act,
                         int out_nchw, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0) return PPEA_ERR_ARG;
-    if ((Cin % 8) != 0 || R < 1 || S < 1 || R > 7 || S > 7 || (stride != 1 && stride != 2) || dil < 1 || pad < 0)
+    if ((Cin % 8) != 0 || R != S || (R != 1 && R != 3 && R != 7) || (stride != 1 && stride != 2) || dil < 1 || pad < 0)
         return PPEA_ERR_UNSUPPORTED;
     if (reflect && (pad > 1 || dil != 1 || H < 2 || W < 2)) return PPEA_ERR_UNSUPPORTED;
+    if ((long)H * W * Cin >= (1L << 31)) return PPEA_ERR_UNSUPPORTED;
     ConvArgs a;
     a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_packed; a.bias = bias; a.y = (uint16_t*)y;
-    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout; a.R = R; a.S = S;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.CinP = (Cin + 31) / 32 * 32; a.Cout = Cout;
     a.stride = stride; a.pad = pad; a.reflect = reflect; a.dil = dil; a.Ho = Ho; a.Wo = Wo; a.act = act;
     a.bias_bf16 = bias_bf16;
-    a.tiles_x = (Wo + TW - 1) / TW; a.tiles_y = (Ho + TH - 1) / TH;
     hipStream_t st = (hipStream_t)stream;
-    if (stride == 1) return out_nchw ? dispatch_conv<1, true>(a, st) : dispatch_conv<1, false>(a, st);
-    return out_nchw ? dispatch_conv<2, true>(a, st) : dispatch_conv<2, false>(a, st);
+    if (stride == 1) return out_nchw ? dispatch_conv<1, true>(a, R, st) : dispatch_conv<1, false>(a, R, st);
+    return out_nchw ? dispatch_conv<2, true>(a, R, st) : dispatch_conv<2, false>(a, R, st);
 }
 
 }  // extern "C"

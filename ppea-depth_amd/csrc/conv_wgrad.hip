@@ -25,41 +25,54 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-constexpr int TH = 8, TW = 16, BM = 64, BN = 64, ROW = 128;     // LDS row = 64 channels x 2 B
+constexpr int TILE_PX = 128;          // output pixels per staged patch: TR rows x TC columns (4 K steps of 32 pixels)
 constexpr int MAX_TAPS = 9;
 
 __device__ __forceinline__ float bf2f(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
-__device__ __forceinline__ int swz(int row) { return 4 * ((row >> 1) & 1) + 8 * ((row >> 3) & 1); }   // 8-byte chunks
+// XOR on the 8-byte chunk index of an LDS row of CH channels (bank windows of the transposing reads, see header)
+template <int CH> __device__ __forceinline__ int swz(int row) {
+    if constexpr (CH == 64) return 4 * ((row >> 1) & 1) + 8 * ((row >> 3) & 1);
+    else return 4 * ((row >> 3) & 1);
+}
 
 struct WgArgs {
     const uint16_t* dz;     // [N][Ho][Wo][Cout]
     const uint16_t* x;      // [N][H][W][Cin]
-    float* ws;              // [splits][R*S][CoutP][CinP] fp32, CoutP / CinP = rounded up to 64
-    int N, H, W, Cin, Cout, R, S, stride, pad, reflect, Ho, Wo;
-    int tiles_x, tiles_y, n_patches, splits, rows_per_block, CoutP, CinP;
+    float* ws;              // [slabs][R*S][CoutP][CinP] fp32
+    int N, H, W, Cin, Cout, pad, reflect, Ho, Wo;
+    int TR, TC, tiles_x, tiles_y, n_patches, splits, rows_per_block, CoutP, CinP;
 };
 
-constexpr int max_x(int stride, int kmax) { return (((TH - 1) * stride + kmax) * ((TW - 1) * stride + kmax) * 8 + 255) / 256; }
+constexpr int halo_cap(int stride, int ks) {
+    return ks <= 3 ? (stride == 1 ? 4 * 66 : 9 * 65) : (stride == 1 ? 14 * 22 : 21 * 37);
+}
 
-template <int STRIDE, int KMAX>
+// BM x BN (co x ci) tile per workgroup; the four waves split it in 32 x 32 pieces and, when the tile has fewer than
+// four, the K steps of a patch among themselves (each wave then writes its own partial slab).
+template <int STRIDE, int KS, int BM, int BN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
-    constexpr int MAX_X = max_x(STRIDE, KMAX);
+    constexpr int NMN = (BM / 32) * (BN / 32), WK = 4 / NMN;
+    constexpr int ZROW = BM * 2, XROW = BN * 2;                 // LDS row bytes
+    constexpr int ZCH = BM / 8, XCH = BN / 8;                   // 16-byte chunks per row
+    constexpr int MAX_Z = TILE_PX * ZCH / 256;
+    constexpr int MAX_X = (halo_cap(STRIDE, KS) * XCH + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int R = a.R, S = a.S;
-    const int HALO_H = (TH - 1) * STRIDE + R, HALO_W = (TW - 1) * STRIDE + S;
+    const int TR = a.TR, TC = a.TC;
+    const int HALO_H = (TR - 1) * STRIDE + KS, HALO_W = (TC - 1) * STRIDE + KS;
     const int halo_px = HALO_H * HALO_W;
-    uint8_t* ldsZ = lds;                               // [128 px][64 co]
-    uint8_t* ldsX = lds + TH * TW * ROW;               // [halo px][64 ci]
+    uint8_t* ldsZ = lds;                               // [128 px][BM co]
+    uint8_t* ldsX = lds + TILE_PX * ZROW;              // [halo px][BN ci]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;           // 2 x 2 waves, 32 x 32 each
+    const int wk = wave / NMN, wmn = wave % NMN;
+    const int wm = wmn / (BN / 32), wn = wmn % (BN / 32);
     const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
     const int co0 = blockIdx.x * BM, ci0 = blockIdx.y * BN;
-    const int rgroups = (R + a.rows_per_block - 1) / a.rows_per_block;
+    const int rgroups = (KS + a.rows_per_block - 1) / a.rows_per_block;
     const int split = blockIdx.z / rgroups;
     const int r0 = (blockIdx.z % rgroups) * a.rows_per_block;
-    const int nr = (R - r0) < a.rows_per_block ? (R - r0) : a.rows_per_block;
-    const int ntap = nr * S;                           // <= MAX_TAPS
+    const int nr = (KS - r0) < a.rows_per_block ? (KS - r0) : a.rows_per_block;
+    const int ntap = nr * KS;                          // <= MAX_TAPS
 
     f32x4 acc[MAX_TAPS][2][2];
 #pragma unroll
@@ -69,22 +82,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[t][i][j] = {0.f, 0.f, 0.f, 0.f};
 
-    const int x_chunks = halo_px * 8;
-    uint4 z_reg[4], x_reg[MAX_X];
+    const int x_chunks = halo_px * XCH;
+    uint4 z_reg[MAX_Z], x_reg[MAX_X];
 
     auto load_patch = [&](int patch) {
         int t = patch;
         const int tx = t % a.tiles_x; t /= a.tiles_x;
         const int ty = t % a.tiles_y;
         const int n = t / a.tiles_y;
-        const int oh0 = ty * TH, ow0 = tx * TW;
+        const int oh0 = ty * TR, ow0 = tx * TC;
         const uint16_t* zn = a.dz + (long)n * a.Ho * a.Wo * a.Cout;
         const uint16_t* xn = a.x + (long)n * a.H * a.W * a.Cin;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int idx = tid + c * 256, px = idx >> 3, ch = co0 + (idx & 7) * 8;
-            const int oh = oh0 + px / TW, ow = ow0 + px % TW;
-            z_reg[c] = (oh < a.Ho && ow < a.Wo && ch < a.Cout)
+        for (int c = 0; c < MAX_Z; ++c) {
+            const int idx = tid + c * 256, px = idx / ZCH, ch = co0 + (idx % ZCH) * 8;
+            const int oh = oh0 + px / TC, ow = ow0 + px % TC;
+            z_reg[c] = (px < TR * TC && oh < a.Ho && ow < a.Wo && ch < a.Cout)
                            ? *reinterpret_cast<const uint4*>(zn + ((long)oh * a.Wo + ow) * a.Cout + ch) : make_uint4(0, 0, 0, 0);
         }
         const int ih0 = oh0 * STRIDE - a.pad, iw0 = ow0 * STRIDE - a.pad;
@@ -92,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
         for (int c = 0; c < MAX_X; ++c) {
             const int idx = tid + c * 256;
             if (idx < x_chunks) {
-                const int px = idx >> 3, ch = ci0 + (idx & 7) * 8;
+                const int px = idx / XCH, ch = ci0 + (idx % XCH) * 8;
                 int ih = ih0 + px / HALO_W, iw = iw0 + px % HALO_W;
                 if (a.reflect) {
                     ih = ih < 0 ? -ih : (ih >= a.H ? 2 * a.H - 2 - ih : ih);
@@ -107,23 +120,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
     };
     auto store_patch = [&]() {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int idx = tid + c * 256, row = idx >> 3;
-            *reinterpret_cast<uint4*>(ldsZ + row * ROW + ((((idx & 7) * 2) ^ swz(row)) << 3)) = z_reg[c];
+        for (int c = 0; c < MAX_Z; ++c) {
+            const int idx = tid + c * 256, row = idx / ZCH;
+            *reinterpret_cast<uint4*>(ldsZ + row * ZROW + ((((idx % ZCH) * 2) ^ swz<BM>(row)) << 3)) = z_reg[c];
         }
 #pragma unroll
         for (int c = 0; c < MAX_X; ++c) {
             const int idx = tid + c * 256;
             if (idx < x_chunks) {
-                const int row = idx >> 3;
-                *reinterpret_cast<uint4*>(ldsX + row * ROW + ((((idx & 7) * 2) ^ swz(row)) << 3)) = x_reg[c];
+                const int row = idx / XCH;
+                *reinterpret_cast<uint4*>(ldsX + row * XROW + ((((idx % XCH) * 2) ^ swz<BN>(row)) << 3)) = x_reg[c];
             }
         }
     };
-    auto tr8 = [&](const uint8_t* base, int row_lo, int row_hi, int chunk0) -> bf16x8 {
-        // rows row_lo (+q handled by the caller) ... : two transposing reads, 4 contraction rows each
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + row_lo * ROW + (((chunk0 + p) ^ swz(row_lo)) << 3)));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base + row_hi * ROW + (((chunk0 + p) ^ swz(row_hi)) << 3)));
+    auto tr_z = [&](int row_lo, int row_hi, int chunk0) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ldsZ + row_lo * ZROW + (((chunk0 + p) ^ swz<BM>(row_lo)) << 3)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ldsZ + row_hi * ZROW + (((chunk0 + p) ^ swz<BM>(row_hi)) << 3)));
+        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, both);
+    };
+    auto tr_x = [&](int row_lo, int row_hi, int chunk0) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ldsX + row_lo * XROW + (((chunk0 + p) ^ swz<BN>(row_lo)) << 3)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ldsX + row_hi * XROW + (((chunk0 + p) ^ swz<BN>(row_hi)) << 3)));
         const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, both);
     };
@@ -136,24 +154,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
         __syncthreads();
         if (patch + a.splits < a.n_patches) load_patch(patch + a.splits);   // in flight under the MFMAs below
 #pragma unroll 1
-        for (int kk = 0; kk < TH / 2; ++kk) {          // K steps of 32 pixels = patch rows 2kk, 2kk+1
-            // lane (g, q, p): contraction rows k = 8g + q (lo) and 8g + 4 + q (hi): patch row 2kk + (g >> 1),
-            // patch columns 8 (g & 1) + q and + 4
-            const int prow = 2 * kk + (g >> 1), pcol = 8 * (g & 1) + q;
+        for (int kk = wk; kk < TILE_PX / 32; kk += WK) {
+            // lane (g, q, p): contraction rows = linear tile pixels k = 32 kk + 8 g + q (lo) and + 4 (hi)
+            const int k_lo = 32 * kk + 8 * g + q, k_hi = k_lo + 4;
+            // halo rows of the two pixels for tap (0, 0); pixels past the tile (TR * TC < 128) carry dz = 0: any row
+            const int m_lo = k_lo < TR * TC ? k_lo : 0, m_hi = k_hi < TR * TC ? k_hi : 0;
+            const int x_lo = (m_lo / TC) * STRIDE * HALO_W + (m_lo % TC) * STRIDE;
+            const int x_hi = (m_hi / TC) * STRIDE * HALO_W + (m_hi % TC) * STRIDE;
             bf16x8 af[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int zr = prow * TW + pcol;
-                af[i] = tr8(ldsZ, zr, zr + 4, (wm * 32 + i * 16) >> 2);
-            }
+            for (int i = 0; i < 2; ++i) af[i] = tr_z(k_lo, k_hi, (wm * 32 + i * 16) >> 2);
 #pragma unroll
             for (int t = 0; t < MAX_TAPS; ++t) {
                 if (t < ntap) {                        // wave-uniform
-                    const int r = r0 + t / S, s = t % S;
-                    const int xr = (prow * STRIDE + r) * HALO_W + pcol * STRIDE + s;
+                    const int off = (r0 + t / KS) * HALO_W + t % KS;
                     bf16x8 bfr[2];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bfr[j] = tr8(ldsX, xr, xr + 4 * STRIDE, (wn * 32 + j * 16) >> 2);
+                    for (int j = 0; j < 2; ++j) bfr[j] = tr_x(x_lo + off, x_hi + off, (wn * 32 + j * 16) >> 2);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -164,12 +181,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
         }
     }
 
-    // partials: C column = li = ci, row = 4 g + e = co
+    // partials: C column = li = ci, row = 4 g + e = co; one slab per (split, K-share of the wave)
 #pragma unroll
     for (int t = 0; t < MAX_TAPS; ++t) {
         if (t >= ntap) continue;
-        const int tap = (r0 + t / S) * S + t % S;
-        float* base = a.ws + (((long)split * R * S + tap) * a.CoutP) * a.CinP;
+        const int tap = (r0 + t / KS) * KS + t % KS;
+        float* base = a.ws + (((long)(split * WK + wk) * KS * KS + tap) * a.CoutP) * a.CinP;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -182,8 +199,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
     }
 }
 
-// sum over splits, write dW in parameter layout [Cout][Cin][R][S] (fp32 or bf16)
-__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, void* __restrict__ dw, int dw_bf16, int splits, int RS,
+// sum over slabs, write dW in parameter layout [Cout][Cin][R][S] (fp32 or bf16)
+__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, void* __restrict__ dw, int dw_bf16, int slabs, int RS,
                                          int Cout, int Cin, int CoutP, int CinP) {
     const long total = (long)Cout * Cin * RS;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -192,31 +209,46 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, void* __r
         const int co = (int)((i / Cin) % Cout);
         const int tap = (int)(i / ((long)Cin * Cout));
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += ws[(((long)k * RS + tap) * CoutP + co) * CinP + ci];
+        for (int k = 0; k < slabs; ++k) s += ws[(((long)k * RS + tap) * CoutP + co) * CinP + ci];
         const long o = ((long)co * Cin + ci) * RS + tap;
         if (dw_bf16) reinterpret_cast<uint16_t*>(dw)[o] = f32_to_bf16(s);
         else reinterpret_cast<float*>(dw)[o] = s;
     }
 }
 
-struct WgPlan { int splits, rows_per_block, rgroups, CoutP, CinP, n_patches, tiles_x, tiles_y; long ws_bytes; };
+struct WgPlan { int BM, BN, WK, splits, slabs, rows_per_block, rgroups, CoutP, CinP, n_patches, TR, TC, tiles_x, tiles_y; long ws_bytes; };
 
-WgPlan plan(int N, int Cin, int Cout, int R, int S, int Ho, int Wo) {
+WgPlan plan(int N, int Cin, int Cout, int K, int stride, int Ho, int Wo) {
     WgPlan p;
-    p.tiles_x = (Wo + TW - 1) / TW; p.tiles_y = (Ho + TH - 1) / TH;
+    // tile of output pixels with the least padding (same candidates as the forward kernel)
+    p.TR = 8; p.TC = 16;
+    long best = (long)((Ho + 7) / 8) * ((Wo + 15) / 16);
+    const int cand[3][2] = {{4, 32}, {2, 64}, {Wo <= 64 ? TILE_PX / Wo : 0, Wo}};
+    for (int c = 0; c < 3; ++c) {
+        int tr = cand[c][0], tc = cand[c][1];
+        if (tr <= 0 || tc <= 0) continue;
+        if (tr > Ho) tr = Ho;
+        if (((tr - 1) * stride + K) * ((tc - 1) * stride + K) > halo_cap(stride, K)) continue;
+        const long tiles = (long)((Ho + tr - 1) / tr) * ((Wo + tc - 1) / tc);
+        if (tiles < best) { best = tiles; p.TR = tr; p.TC = tc; }
+    }
+    p.tiles_x = (Wo + p.TC - 1) / p.TC; p.tiles_y = (Ho + p.TR - 1) / p.TR;
     p.n_patches = p.tiles_x * p.tiles_y * N;
-    p.CoutP = (Cout + BM - 1) / BM * BM; p.CinP = (Cin + BN - 1) / BN * BN;
-    p.rows_per_block = (R * S <= MAX_TAPS) ? R : (MAX_TAPS / S > 0 ? MAX_TAPS / S : 1);
-    p.rgroups = (R + p.rows_per_block - 1) / p.rows_per_block;
-    const long tiles = (long)(p.CoutP / BM) * (p.CinP / BN) * p.rgroups;
-    const long per_split = (long)R * S * p.CoutP * p.CinP * 4;
-    long splits = (768 + tiles - 1) / tiles;                         // enough workgroups to fill 256 CUs three times
-    const long cap = (64L << 20) / per_split;                        // workspace <= 64 MB
+    p.BM = Cout > 32 ? 64 : 32; p.BN = Cin > 32 ? 64 : 32;
+    p.WK = 4 / ((p.BM / 32) * (p.BN / 32));
+    p.CoutP = (Cout + p.BM - 1) / p.BM * p.BM; p.CinP = (Cin + p.BN - 1) / p.BN * p.BN;
+    p.rows_per_block = (K * K <= MAX_TAPS) ? K : (MAX_TAPS / K > 0 ? MAX_TAPS / K : 1);
+    p.rgroups = (K + p.rows_per_block - 1) / p.rows_per_block;
+    const long tiles = (long)(p.CoutP / p.BM) * (p.CinP / p.BN) * p.rgroups;
+    const long per_slab = (long)K * K * p.CoutP * p.CinP * 4;
+    long splits = (512 + tiles - 1) / tiles;                         // two waves of workgroups on 256 CUs
+    const long cap = (32L << 20) / (per_slab * p.WK);                // workspace <= 32 MB
     if (splits > cap) splits = cap;
     if (splits > p.n_patches) splits = p.n_patches;
     if (splits < 1) splits = 1;
     p.splits = (int)splits;
-    p.ws_bytes = per_split * splits;
+    p.slabs = p.splits * p.WK;
+    p.ws_bytes = per_slab * p.slabs;
     return p;
 }
 
@@ -224,8 +256,9 @@ WgPlan plan(int N, int Cin, int Cout, int R, int S, int Ho, int Wo) {
 
 extern "C" {
 
-long ppea_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int R, int S, int Ho, int Wo) {
-    return plan(N, Cin, Cout, R, S, Ho, Wo).ws_bytes;
+long ppea_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int R, int S, int stride, int Ho, int Wo) {
+    if (R != S) return 0;
+    return plan(N, Cin, Cout, R, stride, Ho, Wo).ws_bytes;
 }
 
 // dz [N][Ho][Wo][Cout], x [N][H][W][Cin] channels-last bf16 (Cin % 8 == 0, Cout % 8 == 0); dw [Cout][Cin][R][S] fp32 or
@@ -233,23 +266,23 @@ long ppea_conv_wgrad_workspace_bytes(int N, int Cin, int Cout, int R, int S, int
 int ppea_conv_wgrad_nhwc_bf16(const void* dz, const void* x, void* dw, int dw_bf16, void* workspace, int N, int H, int W,
                               int Cin, int Cout, int R, int S, int stride, int pad, int reflect, int Ho, int Wo, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 || !workspace) return PPEA_ERR_ARG;
-    if ((Cin % 8) != 0 || (Cout % 8) != 0 || R < 1 || S < 1 || R > 7 || S > 7 || (stride != 1 && stride != 2) || pad < 0)
+    if ((Cin % 8) != 0 || (Cout % 8) != 0 || R != S || (R != 1 && R != 3 && R != 7) || (stride != 1 && stride != 2) || pad < 0)
         return PPEA_ERR_UNSUPPORTED;
     if (reflect && (pad > 1 || H < 2 || W < 2)) return PPEA_ERR_UNSUPPORTED;
-    const WgPlan p = plan(N, Cin, Cout, R, S, Ho, Wo);
+    const WgPlan p = plan(N, Cin, Cout, R, stride, Ho, Wo);
     WgArgs a;
     a.dz = (const uint16_t*)dz; a.x = (const uint16_t*)x; a.ws = (float*)workspace;
-    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
-    a.reflect = reflect; a.Ho = Ho; a.Wo = Wo; a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.n_patches = p.n_patches;
-    a.splits = p.splits; a.rows_per_block = p.rows_per_block; a.CoutP = p.CoutP; a.CinP = p.CinP;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.pad = pad;
+    a.reflect = reflect; a.Ho = Ho; a.Wo = Wo; a.TR = p.TR; a.TC = p.TC; a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y;
+    a.n_patches = p.n_patches; a.splits = p.splits; a.rows_per_block = p.rows_per_block; a.CoutP = p.CoutP; a.CinP = p.CinP;
     hipStream_t st = (hipStream_t)stream;
-    const int halo_px = ((TH - 1) * stride + R) * ((TW - 1) * stride + S);
-    const size_t smem = (size_t)(TH * TW + halo_px) * ROW;
+    const int halo_px = ((p.TR - 1) * stride + R) * ((p.TC - 1) * stride + R);
+    const size_t smem = (size_t)TILE_PX * p.BM * 2 + (size_t)halo_px * p.BN * 2;
     if (smem > 160 * 1024) return PPEA_ERR_UNSUPPORTED;
-    const dim3 grid(p.CoutP / BM, p.CinP / BN, p.splits * p.rgroups);
-#define WG_LAUNCH(STRIDE_, KMAX_)                                                                                       \
+    const dim3 grid(p.CoutP / p.BM, p.CinP / p.BN, p.splits * p.rgroups);
+#define WG_LAUNCH(STRIDE_, KS_, BM_, BN_)                                                                               \
     do {                                                                                                                \
-        auto kern = conv_wgrad_kernel<STRIDE_, KMAX_>;                                                                  \
+        auto kern = conv_wgrad_kernel<STRIDE_, KS_, BM_, BN_>;                                                          \
         if (smem > 64 * 1024) {                                                                                         \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                   \
@@ -257,16 +290,23 @@ int ppea_conv_wgrad_nhwc_bf16(const void* dz, const void* x, void* dw, int dw_bf
         }                                                                                                               \
         hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);                                                         \
     } while (0)
-    const bool wide = R > 3 || S > 3;
-    if (stride == 1) { if (wide) WG_LAUNCH(1, 7); else WG_LAUNCH(1, 3); }
-    else { if (wide) WG_LAUNCH(2, 7); else WG_LAUNCH(2, 3); }
+#define WG_TILES(STRIDE_, KS_)                                                                                          \
+    do {                                                                                                                \
+        if (p.BM == 64 && p.BN == 64) WG_LAUNCH(STRIDE_, KS_, 64, 64);                                                  \
+        else if (p.BM == 64) WG_LAUNCH(STRIDE_, KS_, 64, 32);                                                           \
+        else if (p.BN == 64) WG_LAUNCH(STRIDE_, KS_, 32, 64);                                                           \
+        else WG_LAUNCH(STRIDE_, KS_, 32, 32);                                                                           \
+    } while (0)
+    if (stride == 1) { if (R == 1) WG_TILES(1, 1); else if (R == 3) WG_TILES(1, 3); else WG_TILES(1, 7); }
+    else { if (R == 1) WG_TILES(2, 1); else if (R == 3) WG_TILES(2, 3); else WG_TILES(2, 7); }
+#undef WG_TILES
 #undef WG_LAUNCH
     int err = launch_status();
     if (err) return err;
     const long total = (long)Cout * Cin * R * S;
     const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, dw_bf16,
-                       p.splits, R * S, Cout, Cin, p.CoutP, p.CinP);
+                       p.slabs, R * S, Cout, Cin, p.CoutP, p.CinP);
     return launch_status();
 }
 

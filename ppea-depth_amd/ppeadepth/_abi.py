@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libppea_depth.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -101,7 +101,7 @@ SIGNATURES = {
     "ppea_conv_pack_weights": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "ppea_image_to_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
     "ppea_conv_nhwc_bf16": [_vp, _vp, _vp, _i, _vp] + [_i] * 15 + [_vp],
-    "ppea_conv_wgrad_workspace_bytes": [_i] * 7,
+    "ppea_conv_wgrad_workspace_bytes": [_i] * 8,
     "ppea_conv_wgrad_nhwc_bf16": [_vp, _vp, _vp, _i, _vp] + [_i] * 12 + [_vp],
     "ppea_cost_volume_fwd_f32": [_vp] * 7 + [_i] * 5 + [_f, _vp],
     "ppea_cost_volume_reduce_f32": [_vp] * 6 + [_i] * 4 + [_vp],

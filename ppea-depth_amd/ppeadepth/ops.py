@@ -929,6 +929,8 @@ def conv_module(conv, x, act="none", reflect=False, out_nchw=False):
         x = image_to_nhwc(x, 8)
     if x.dtype != _BF16 or x.shape[1] % 8 != 0:
         return None
+    if reflect and (x.shape[2] < 3 or x.shape[3] < 3):        # the fold kernel of the data gradient needs a 3 x 3 interior
+        return None
     return conv2d_nhwc(x, conv.weight, conv.bias, conv.stride[0], 1 if reflect else conv.padding[0], reflect, act, out_nchw)
 _CONV_PACK_CACHE = {}
 
@@ -1039,7 +1041,7 @@ class _ConvNhwc(torch.autograd.Function):
             if Cout % 8 != 0:
                 raise _abi.PpeaKernelError("conv weight gradient: output channels must be a multiple of 8 "
                                            "(pad the layer, see conv2d_nhwc)")
-            ws = torch.empty(_abi.lib.ppea_conv_wgrad_workspace_bytes(N, Cin, Cout, R, S, Ho, Wo) // 4, device=dz.device,
+            ws = torch.empty(_abi.lib.ppea_conv_wgrad_workspace_bytes(N, Cin, Cout, R, S, stride, Ho, Wo) // 4, device=dz.device,
                              dtype=_F32)
             gdt = w.dtype if w.dtype in (_BF16, _F32) else _F32
             dw = torch.empty(Cout, Cin, R, S, device=dz.device, dtype=gdt)
