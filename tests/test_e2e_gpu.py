@@ -240,14 +240,14 @@ class _plain_torch_bf16:
     def __enter__(self):
         from ppeadepth import ops
         from ppeadepth.networks import replknet_adapter as rka
-        self.saved = (rka.FUSE_BN, rka.PW_MFMA, rka.ADAPTER_MFMA, ops._MFMA_K)
-        rka.FUSE_BN = rka.PW_MFMA = rka.ADAPTER_MFMA = False
+        self.saved = (rka.FUSE_BN, rka.PW_MFMA, rka.ADAPTER_MFMA, ops._MFMA_K, ops.CONV_MFMA)
+        rka.FUSE_BN = rka.PW_MFMA = rka.ADAPTER_MFMA = ops.CONV_MFMA = False
         ops._MFMA_K = ()
 
     def __exit__(self, *exc):
         from ppeadepth import ops
         from ppeadepth.networks import replknet_adapter as rka
-        rka.FUSE_BN, rka.PW_MFMA, rka.ADAPTER_MFMA, ops._MFMA_K = self.saved
+        rka.FUSE_BN, rka.PW_MFMA, rka.ADAPTER_MFMA, ops._MFMA_K, ops.CONV_MFMA = self.saved
 
 
 # Absolute caps for the bf16 step (2x the values measured with tools/debug_bf16.py, profiles/r02_bf16_step_parity.txt).

@@ -27,6 +27,7 @@ def switches(**kw):
     rka.ADAPTER_MFMA = kw.get("adapter", True)
     ops._MFMA_K = (31, 29, 27, 13) if kw.get("dw", True) else ()
     rka.ADAPTER_STREAMS = kw.get("streams", True)
+    ops.CONV_MFMA = kw.get("conv", True)
 
 
 def block(kind, C, K, H, W, dev):
@@ -76,7 +77,7 @@ def block(kind, C, K, H, W, dev):
 def e2e(name, dev):
     import test_e2e_gpu as T
     g = load_golden(name)
-    for tag, kw in (("all kernels", {}), ("plain torch bf16", dict(dw=False, pw=False, adapter=False, fuse_bn=False))):
+    for tag, kw in (("all kernels", {}), ("plain torch bf16", dict(dw=False, pw=False, adapter=False, fuse_bn=False, conv=False))):
         switches(**kw)
         res = T._engine_step(name, lambda n: g, dev, bf16=True, graph=False, **T.CONFIG_OF.get(name, {}))
         errs = T._errors(*res)
