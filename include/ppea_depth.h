@@ -164,6 +164,21 @@ int ppea_bn_stats_packed_f32(const void* z, int N, int C, int HW, float* packed,
 int ppea_bn_stats_packed_bf16(const void* z, int N, int C, int HW, float* packed, void* stream);
 int ppea_bn_sync_combine_f32(const float* gathered, int world, int C, float eps, float momentum, float* mean,
                              float* invstd, float* running_mean, float* running_var, void* stream);
+/* One launch per BN and direction for small channels (N * HW <= 16384, HW % 8 == 0, C >= 64): the workgroup that
+ * owns a channel keeps its values in registers, so statistics + apply (forward) and reduce + apply (backward) are one
+ * kernel each.  prm = {gamma1, beta1, gamma2, beta2}; out = {running_mean1, running_var1, running_mean2, running_var2
+ * (NULL: no update), mean1, invstd1, mean2, invstd2 (written)}; `sums` [3][C] as ppea_bn_bwd_reduce_final_*.
+ * Same semantics as rka.py:182-197, 232-239, 283-289, 315-326 (training-mode BN + act + DropPath + residuals). */
+int ppea_bn_fwd_channel_f32(const void* z1, const void* z2, const float* const* prm, float* const* out, float eps,
+                            float momentum, const float* mask, const void* r1, const void* r2, float r2_scale, void* y,
+                            int act, int N, int C, int HW, void* stream);
+int ppea_bn_fwd_channel_bf16(const void* z1, const void* z2, const float* const* prm, float* const* out, float eps,
+                             float momentum, const float* mask, const void* r1, const void* r2, float r2_scale, void* y,
+                             int act, int N, int C, int HW, void* stream);
+int ppea_bn_bwd_channel_f32(const void* dy, const void* z1, const void* z2, const float* const* stats, const float* mask,
+                            float inv_count, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW, void* stream);
+int ppea_bn_bwd_channel_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats, const float* mask,
+                             float inv_count, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW, void* stream);
 int ppea_bn_apply_f32(const void* z1, const void* z2, const float* const* stats, const float* mask,
                       const void* r1, const void* r2, float r2_scale, void* y, int act,
                       int N, int C, int HW, void* stream);

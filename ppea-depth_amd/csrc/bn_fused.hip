@@ -503,6 +503,161 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_channel(const T* __restrict
     if (threadIdx.x == 0) { sums[c] = sg; sums[C + c] = s1; sums[2 * C + c] = s2; }
 }
 
+// ---- one launch per BN and direction for small channels ---------------------------------------------------------------
+// The workgroup that owns a channel holds ALL of its values in registers, so the statistics pass and the apply pass
+// are the same kernel: z is read once (not twice) and the BN costs one launch forward and one backward instead of two
+// each (stages 2 and 3 of both encoders: 40 of the 48 blocks).  Same arithmetic as bn_stats_channel + bn_apply_flat
+// and bn_bwd_reduce_channel + bn_bwd_apply_flat.
+struct FwdPrm { const float *gamma1, *beta1, *gamma2, *beta2; float *rm1, *rv1, *rm2, *rv2, *mean1, *invstd1, *mean2, *invstd2; };
+
+template <typename T, bool TWO>
+__global__ __launch_bounds__(TPB) void bn_fwd_channel(const T* __restrict__ z1, const T* __restrict__ z2, FwdPrm p,
+                                                      float eps, float momentum, const float* __restrict__ mask,
+                                                      const T* __restrict__ r1, const T* __restrict__ r2,
+                                                      float r2_scale, T* __restrict__ y, int act, int N, int C, int HW) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const int hv = HW / V, total = N * hv;
+    const float cnt = (float)N * (float)HW;
+    float x1[CH_VECS][V], x2[TWO ? CH_VECS : 1][V];
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j < total) {
+            const int n = j / hv, i = j - n * hv;
+            const long off = ((long)n * C + c) * HW + i * V;
+            ld8<T>(z1 + off, x1[u]);
+            if constexpr (TWO) ld8<T>(z2 + off, x2[u]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) { x1[u][k] = 0.f; if constexpr (TWO) x2[u][k] = 0.f; }
+        }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u)
+#pragma unroll
+        for (int k = 0; k < V; ++k) { s1 += x1[u][k]; if constexpr (TWO) s2 += x2[u][k]; }
+    const float mu1 = block_sum(s1, red) / cnt;
+    float mu2 = 0.f;
+    if constexpr (TWO) mu2 = block_sum(s2, red) / cnt;
+    float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u)
+        if (threadIdx.x + u * TPB < total) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                q1 += (x1[u][k] - mu1) * (x1[u][k] - mu1);
+                if constexpr (TWO) q2 += (x2[u][k] - mu2) * (x2[u][k] - mu2);
+            }
+        }
+    q1 = block_sum(q1, red);
+    if constexpr (TWO) q2 = block_sum(q2, red);
+    const float is1 = rsqrtf(q1 / cnt + eps), is2 = TWO ? rsqrtf(q2 / cnt + eps) : 0.f;
+    if (threadIdx.x == 0) {
+        p.mean1[c] = mu1; p.invstd1[c] = is1;
+        if (p.rm1 != nullptr) {
+            p.rm1[c] = (1.f - momentum) * p.rm1[c] + momentum * mu1;
+            p.rv1[c] = (1.f - momentum) * p.rv1[c] + momentum * (q1 / fmaxf(cnt - 1.f, 1.f));
+        }
+        if constexpr (TWO) {
+            p.mean2[c] = mu2; p.invstd2[c] = is2;
+            if (p.rm2 != nullptr) {
+                p.rm2[c] = (1.f - momentum) * p.rm2[c] + momentum * mu2;
+                p.rv2[c] = (1.f - momentum) * p.rv2[c] + momentum * (q2 / fmaxf(cnt - 1.f, 1.f));
+            }
+        }
+    }
+    const float a1 = p.gamma1[c] * is1, o1 = p.beta1[c] - mu1 * a1;
+    float a2 = 0.f, o2 = 0.f;
+    if constexpr (TWO) { a2 = p.gamma2[c] * is2; o2 = p.beta2[c] - mu2 * a2; }
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j >= total) break;
+        const int n = j / hv, i = j - n * hv;
+        const long off = ((long)n * C + c) * HW + i * V;
+        const float m = (mask != nullptr) ? mask[n] : 1.f;
+        float e1[V], e2[V], o[V];
+        if (r1 != nullptr) ld8<T>(r1 + off, e1);
+        if (r2 != nullptr) ld8<T>(r2 + off, e2);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float w = a1 * x1[u][k] + o1;
+            if constexpr (TWO) w += a2 * x2[u][k] + o2;
+            float v = act_fwd(w, act) * m;
+            if (r1 != nullptr) v += e1[k];
+            if (r2 != nullptr) v += r2_scale * e2[k];
+            o[k] = v;
+        }
+        st8<T>(y + off, o);
+    }
+}
+
+template <typename T, bool TWO>
+__global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, const T* __restrict__ z1,
+                                                      const T* __restrict__ z2, Branch b1, Branch b2,
+                                                      const float* __restrict__ mask, float inv_count,
+                                                      T* __restrict__ dz1, T* __restrict__ dz2,
+                                                      float* __restrict__ sums, int act, int N, int C, int HW) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const int hv = HW / V, total = N * hv;
+    const float is1 = b1.invstd[c], mu1 = b1.mean[c];
+    const float a1 = b1.gamma[c] * is1, o1 = b1.beta[c] - mu1 * a1;
+    float is2 = 0.f, mu2 = 0.f, a2 = 0.f, o2 = 0.f;
+    if constexpr (TWO) { is2 = b2.invstd[c]; mu2 = b2.mean[c]; a2 = b2.gamma[c] * is2; o2 = b2.beta[c] - mu2 * a2; }
+    float x1[CH_VECS][V], x2[TWO ? CH_VECS : 1][V], gq[CH_VECS][V];
+    float sg = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j < total) {
+            const int n = j / hv, i = j - n * hv;
+            const long off = ((long)n * C + c) * HW + i * V;
+            ld8<T>(z1 + off, x1[u]);
+            if constexpr (TWO) ld8<T>(z2 + off, x2[u]);
+            ld8<T>(dy + off, gq[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j < total) {
+            const float m = (mask != nullptr) ? mask[j / hv] : 1.f;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float w = a1 * x1[u][k] + o1;
+                if constexpr (TWO) w += a2 * x2[u][k] + o2;
+                const float g = gq[u][k] * m * act_bwd(w, act);
+                gq[u][k] = g;
+                sg += g;
+                s1 += g * (x1[u][k] - mu1) * is1;
+                if constexpr (TWO) s2 += g * (x2[u][k] - mu2) * is2;
+            }
+        }
+    }
+    sg = block_sum(sg, red); s1 = block_sum(s1, red);
+    if constexpr (TWO) s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) { sums[c] = sg; sums[C + c] = s1; sums[2 * C + c] = s2; }
+    const float mg = sg * inv_count, m1 = s1 * inv_count, m2 = s2 * inv_count;
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j >= total) break;
+        const int n = j / hv, i = j - n * hv;
+        const long off = ((long)n * C + c) * HW + i * V;
+        float e1[V], e2[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            e1[k] = a1 * (gq[u][k] - mg - (x1[u][k] - mu1) * is1 * m1);
+            if constexpr (TWO) e2[k] = a2 * (gq[u][k] - mg - (x2[u][k] - mu2) * is2 * m2);
+        }
+        st8<T>(dz1 + off, e1);
+        if constexpr (TWO) st8<T>(dz2 + off, e2);
+    }
+}
+
 constexpr long CHANNEL_ELEMS = 16384;       // N * HW up to here: the wave-per-channel kernels
 
 // ---- flat element-wise passes (HW % 8 == 0): 8 elements per thread, channel looked up per thread -------
@@ -696,7 +851,59 @@ int bwd_reduce_final_impl(const void* dy, const void* z1, const void* z2, const 
     return launch_status();
 }
 
+template <typename T>
+int fwd_channel_impl(const void* z1, const void* z2, const float* const* prm, float* const* outp, float eps, float momentum,
+                     const float* mask, const void* r1, const void* r2, float r2_scale, void* y, int act, int N, int C, int HW,
+                     void* stream) {
+    if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS || act < 0 || act > 2)
+        return PPEA_ERR_UNSUPPORTED;
+    FwdPrm p{prm[0], prm[1], prm[2], prm[3], outp[0], outp[1], outp[2], outp[3], outp[4], outp[5], outp[6], outp[7]};
+    if (z2 != nullptr)
+        hipLaunchKernelGGL((bn_fwd_channel<T, true>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)z1,
+                           (const T*)z2, p, eps, momentum, mask, (const T*)r1, (const T*)r2, r2_scale, (T*)y, act, N, C, HW);
+    else
+        hipLaunchKernelGGL((bn_fwd_channel<T, false>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)z1,
+                           (const T*)nullptr, p, eps, momentum, mask, (const T*)r1, (const T*)r2, r2_scale, (T*)y, act, N, C, HW);
+    return launch_status();
+}
+template <typename T>
+int bwd_channel_impl(const void* dy, const void* z1, const void* z2, const float* const* st, const float* mask,
+                     float inv_count, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW, void* stream) {
+    if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS || act < 0 || act > 2)
+        return PPEA_ERR_UNSUPPORTED;
+    Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
+    if (z2 != nullptr)
+        hipLaunchKernelGGL((bn_bwd_channel<T, true>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy,
+                           (const T*)z1, (const T*)z2, b1, b2, mask, inv_count, (T*)dz1, (T*)dz2, sums, act, N, C, HW);
+    else
+        hipLaunchKernelGGL((bn_bwd_channel<T, false>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy,
+                           (const T*)z1, (const T*)nullptr, b1, b2, mask, inv_count, (T*)dz1, (T*)nullptr, sums, act, N, C, HW);
+    return launch_status();
+}
+
 extern "C" {
+
+// One launch per BN for small channels (N * HW <= 16384, HW % 8 == 0, C >= 64; else PPEA_ERR_UNSUPPORTED):
+// prm = {gamma1, beta1, gamma2, beta2}; out = {running_mean1, running_var1, running_mean2, running_var2 (NULL: no
+// update), mean1, invstd1, mean2, invstd2 (written; kept for backward)}.  Rest as ppea_bn_apply_* / ppea_bn_bwd_*.
+int ppea_bn_fwd_channel_f32(const void* z1, const void* z2, const float* const* prm, float* const* out, float eps,
+                            float momentum, const float* mask, const void* r1, const void* r2, float r2_scale, void* y,
+                            int act, int N, int C, int HW, void* stream) {
+    return fwd_channel_impl<float>(z1, z2, prm, out, eps, momentum, mask, r1, r2, r2_scale, y, act, N, C, HW, stream);
+}
+int ppea_bn_fwd_channel_bf16(const void* z1, const void* z2, const float* const* prm, float* const* out, float eps,
+                             float momentum, const float* mask, const void* r1, const void* r2, float r2_scale, void* y,
+                             int act, int N, int C, int HW, void* stream) {
+    return fwd_channel_impl<uint16_t>(z1, z2, prm, out, eps, momentum, mask, r1, r2, r2_scale, y, act, N, C, HW, stream);
+}
+int ppea_bn_bwd_channel_f32(const void* dy, const void* z1, const void* z2, const float* const* stats, const float* mask,
+                            float inv_count, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW, void* stream) {
+    return bwd_channel_impl<float>(dy, z1, z2, stats, mask, inv_count, dz1, dz2, sums, act, N, C, HW, stream);
+}
+int ppea_bn_bwd_channel_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats, const float* mask,
+                             float inv_count, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW, void* stream) {
+    return bwd_channel_impl<uint16_t>(dy, z1, z2, stats, mask, inv_count, dz1, dz2, sums, act, N, C, HW, stream);
+}
 
 // stats[8] = {mean1, invstd1, gamma1, beta1, mean2, invstd2, gamma2, beta2} (branch 2 NULL when z2 is NULL)
 int ppea_bn_stats_f32(const void* z, float* partial, int N, int C, int HW, void* stream) {

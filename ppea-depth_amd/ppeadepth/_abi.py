@@ -97,6 +97,10 @@ SIGNATURES = {
     "ppea_smooth_fwd_f32": [_vp] * 3 + [_i] * 4 + [_vp],
     "ppea_smooth_bwd_f32": [_vp, _vp, _f, _f, _vp] + [_i] * 4 + [_vp],
     "ppea_loss_select_f32": [_vp] * 9 + [_i] * 5 + [_vp],
+    "ppea_bn_fwd_channel_f32": [_vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp],
+    "ppea_bn_fwd_channel_bf16": [_vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp],
+    "ppea_bn_bwd_channel_f32": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_bn_bwd_channel_bf16": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_conv_packed_bytes": [_i] * 5,
     "ppea_conv_pack_weights": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "ppea_image_to_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],

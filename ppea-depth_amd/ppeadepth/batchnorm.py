@@ -188,6 +188,20 @@ def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None,
     from . import ops
     assert bn1.training, "fused_bn_act is the training-mode path; eval goes through BatchNorm2d.forward"
     bns = [(z1, bn1)] + ([(z2, bn2)] if z2 is not None else [])
+    # small channels on one rank: statistics, running-statistics update and apply in ONE launch (backward likewise)
+    if (ops.bn_channel_ok(z1) and all(bn.training for _, bn in bns) and not any(bn.sync and _collectives_on() for _, bn in bns)
+            and (bn2 is None or (bn2.eps == bn1.eps and bn2.momentum == bn1.momentum))
+            and bn1.running_mean.dtype == torch.float32):
+        y, st = ops.bn_act_channel(z1, bn1, z2, bn2, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act)
+        cnt = float(z1.numel() // z1.shape[1])
+        for k, (_, bn) in enumerate(bns):
+            if _ACTIVE_DEFERRED is None:
+                bn.num_batches_tracked += 1
+            else:
+                _ACTIVE_DEFERRED.count(bn)
+                if bn.replay_update and torch.is_grad_enabled():
+                    _ACTIVE_DEFERRED.add(bn, st[2 * k], st[2 * k + 1], cnt)
+        return y
     stats = []
     count, group = None, None
     pre = None

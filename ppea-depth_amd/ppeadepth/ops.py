@@ -311,11 +311,14 @@ class _LossSelect(torch.autograd.Function):
              ptr(aidx), B, C, H, W, int(bool(selec)), stream_ptr())
         ctx.save_for_backward(src)
         ctx.mark_non_differentiable(src, fidx, aidx)
+        ctx.set_materialize_grads(False)
         return sel, src, fidx, aidx
 
     @staticmethod
     def backward(ctx, d_sel, _a, _b, _c):
         (src,) = ctx.saved_tensors
+        if d_sel is None:
+            return None, None, None, None, None, None
         d = torch.cat([d_sel * (src == 0), d_sel * (src == 1)], 1)
         return d, None, None, None, None, None
 
@@ -480,6 +483,87 @@ class _BnAct(torch.autograd.Function):
         return (dz1, dg1, db1, None, None, dz2, dg2, db2, None, None, None, dr1, dr2, None, None, None, None)
 
 
+BN_CHANNEL = True          # small channels: statistics + apply (and reduce + apply) as ONE launch each
+
+
+def bn_channel_ok(z):
+    """Whole channel in one workgroup's registers: csrc/bn_fused.hip bn_fwd_channel / bn_bwd_channel."""
+    if not (BN_CHANNEL and z.is_cuda and z.dim() == 4 and z.dtype in (_F32, _BF16)):
+        return False
+    N, C = z.shape[0], z.shape[1]
+    HW = z.shape[2] * z.shape[3]
+    return C >= 64 and HW % 8 == 0 and N * HW <= 16384
+
+
+def _ptr_array(ts):
+    arr = (_ct.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+class _BnActChannel(torch.autograd.Function):
+    """y = act(BN1(z1) [+ BN2(z2)]) [* mask[n]] [+ r1] [+ s * r2] with batch statistics, running-statistics update and
+    the saved (mean, invstd) in ONE launch; backward (sums + dz) in one launch."""
+
+    @staticmethod
+    def forward(ctx, z1, g1, b1, rm1, rv1, z2, g2, b2, rm2, rv2, mask, r1, r2, r2_scale, act, eps, momentum):
+        z1 = z1.contiguous()
+        N, C = z1.shape[0], z1.shape[1]
+        HW = z1.numel() // (N * C)
+        dt = z1.dtype
+        z2 = None if z2 is None else z2.contiguous().to(dt)
+        r1 = None if r1 is None else r1.contiguous().to(dt)
+        r2 = None if r2 is None else r2.contiguous().to(dt)
+        g1f, b1f = g1.detach().float().contiguous(), b1.detach().float().contiguous()
+        g2f = None if g2 is None else g2.detach().float().contiguous()
+        b2f = None if b2 is None else b2.detach().float().contiguous()
+        maskf = None if mask is None else mask.detach().reshape(-1).float().contiguous()
+        st = torch.empty(4, C, device=z1.device, dtype=_F32)          # mean1 | invstd1 | mean2 | invstd2
+        y = torch.empty_like(z1)
+        call(f"ppea_bn_fwd_channel_{_suffix(z1)}", ptr(z1), ptr(z2), _ptr_array((g1f, b1f, g2f, b2f)),
+             _ptr_array((rm1, rv1, rm2, rv2, st[0], st[1], st[2], st[3])), float(eps), float(momentum), ptr(maskf),
+             ptr(r1), ptr(r2), float(r2_scale), ptr(y), int(act), N, C, HW, stream_ptr())
+        ctx.save_for_backward(z1, z2, st, g1f, b1f, g2f, b2f, maskf)
+        ctx.act, ctx.r2_scale = int(act), float(r2_scale)
+        ctx.has = (r1 is not None, r2 is not None)
+        ctx.pdt = (g1.dtype, b1.dtype, None if g2 is None else g2.dtype)
+        ctx.mark_non_differentiable(st)
+        ctx.set_materialize_grads(False)         # no zero-filled "gradient" of the statistics output per backward call
+        return y, st
+
+    @staticmethod
+    def backward(ctx, dy, _dst):
+        z1, z2, st, g1f, b1f, g2f, b2f, maskf = ctx.saved_tensors
+        N, C = z1.shape[0], z1.shape[1]
+        HW = z1.numel() // (N * C)
+        if dy is None:
+            dy = torch.zeros_like(z1)
+        dy = dy.contiguous().to(z1.dtype)
+        sums = torch.empty(3, C, device=z1.device, dtype=_F32)
+        dz1 = torch.empty_like(z1)
+        dz2 = None if z2 is None else torch.empty_like(z2)
+        stats = _stats_array((st[0], st[1], g1f, b1f, st[2] if z2 is not None else None,
+                              st[3] if z2 is not None else None, g2f, b2f))
+        call(f"ppea_bn_bwd_channel_{_suffix(z1)}", ptr(dy), ptr(z1), ptr(z2), stats, ptr(maskf), 1.0 / float(N * HW),
+             ptr(dz1), ptr(dz2), ptr(sums), ctx.act, N, C, HW, stream_ptr())
+        dg1 = sums[1].to(ctx.pdt[0]) if ctx.needs_input_grad[1] else None
+        db1 = sums[0].to(ctx.pdt[1]) if ctx.needs_input_grad[2] else None
+        dg2 = sums[2].to(ctx.pdt[2]) if (z2 is not None and ctx.needs_input_grad[6]) else None
+        db2 = sums[0].to(ctx.pdt[2]) if (z2 is not None and ctx.needs_input_grad[7]) else None
+        dr1 = dy if ctx.has[0] else None
+        dr2 = (dy if ctx.r2_scale == 1.0 else dy * ctx.r2_scale) if ctx.has[1] else None
+        return (dz1, dg1, db1, None, None, dz2, dg2, db2, None, None, None, dr1, dr2, None, None, None, None)
+
+
+def bn_act_channel(z1, bn1, z2=None, bn2=None, mask=None, r1=None, r2=None, r2_scale=1.0, act=ACT_NONE):
+    """-> (y, stats [4,C] = mean1 | invstd1 | mean2 | invstd2).  Updates the running statistics of bn1 / bn2."""
+    return _BnActChannel.apply(z1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, z2,
+                               None if bn2 is None else bn2.weight, None if bn2 is None else bn2.bias,
+                               None if bn2 is None else bn2.running_mean, None if bn2 is None else bn2.running_var,
+                               mask, r1, r2, r2_scale, act, bn1.eps, bn1.momentum)
+
+
 def bn_act_apply(z1, g1, b1, mean1, invstd1, z2=None, g2=None, b2=None, mean2=None, invstd2=None, mask=None,
                  r1=None, r2=None, r2_scale=1.0, act=ACT_NONE, count=None, group=None):
     if count is None:
@@ -529,6 +613,7 @@ class _NhwcBnAct(torch.autograd.Function):
         ctx.save_for_backward(x, res, stats, ab)
         ctx.cfg = (int(act), int(groups), P, C, weight.dtype, bias.dtype)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
         return y, stats
 
     @staticmethod
@@ -537,6 +622,8 @@ class _NhwcBnAct(torch.autograd.Function):
         act, groups, P, C, wdt, bdt = ctx.cfg
         sfx = _suffix(x)
         dev = x.device
+        if dy is None:
+            dy = torch.zeros_like(x)
         dy = dy.contiguous(memory_format=torch.channels_last).to(x.dtype)
         slabs = _abi.lib.ppea_nhwc_bn_slabs(P, C)
         partial = torch.empty(groups * slabs * 2 * C, device=dev, dtype=_F32)

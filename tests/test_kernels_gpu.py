@@ -808,3 +808,62 @@ def test_image_to_nhwc_and_conv_full_size(device):
     y = ops.conv2d_nhwc(xn, w8, None, 2, 3)
     yr = F.conv2d(want.float(), w.float(), None, 2, 3)
     assert rel_err(y.float().cpu(), yr) < 2 ** -7
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("two,act,res", [(False, 0, False), (False, 1, False), (True, 1, False), (False, 2, False),
+                                         (False, 0, True), (True, 1, True)])
+@pytest.mark.parametrize("shape", [(12, 64, 12, 40), (3, 128, 6, 24), (5, 64, 6, 20), (12, 96, 4, 8)])
+def test_bn_channel_one_launch(device, dtype, two, act, res, shape):
+    """Small channels: statistics + running-statistics update + apply in ONE launch (and reduce + apply in one launch
+    backward) -- forward, saved statistics, running statistics and every gradient against the fp32 oracle composite
+    (the same reference as test_fused_bn_act)."""
+    import torch.nn.functional as F
+    from ppeadepth import ops
+    from ppeadepth.batchnorm import BatchNorm2d
+    N, C, H, W = shape
+    g = _g(N * 100 + C + act)
+    dt = torch.float32 if dtype == "f32" else torch.bfloat16
+    z1 = (torch.randn(shape, generator=g) * 2 + 0.5).to(dt)
+    z2 = (torch.randn(shape, generator=g) * 0.7 - 0.2).to(dt)
+    g1, b1 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    g2, b2 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    mask = torch.tensor(([0.0] + [1.4] * N)[:N])
+    r1 = torch.randn(shape, generator=g).to(dt)
+    r2 = torch.randn(shape, generator=g).to(dt)
+    go = torch.randn(shape, generator=g).to(dt)
+    leaves = [t.float().clone().requires_grad_(True) for t in (z1, z2, g1, b1, g2, b2, r1, r2)]
+    a, bb, w1, c1, w2, c2, q1, q2 = leaves
+    rm_ref, rv_ref, rm2_ref, rv2_ref = torch.zeros(C), torch.ones(C), torch.zeros(C), torch.ones(C)
+    u = F.batch_norm(a, rm_ref, rv_ref, w1, c1, True, 0.1, 1e-5)
+    if two:
+        u = u + F.batch_norm(bb, rm2_ref, rv2_ref, w2, c2, True, 0.1, 1e-5)
+    u = F.relu(u) if act == 1 else (F.gelu(u) if act == 2 else u)
+    if res:
+        u = u * mask.view(-1, 1, 1, 1) + q1 + 0.5 * q2
+    (u * go.float()).sum().backward()
+
+    bn1, bn2 = BatchNorm2d(C).to(device), BatchNorm2d(C).to(device)
+    with torch.no_grad():
+        bn1.weight.copy_(g1); bn1.bias.copy_(b1); bn2.weight.copy_(g2); bn2.bias.copy_(b2)
+    d = [t.to(device).requires_grad_(True) for t in (z1, z2, r1, r2)]
+    assert ops.bn_channel_ok(d[0])
+    kw = dict(z2=d[1], bn2=bn2) if two else {}
+    if res:
+        kw.update(mask=mask.to(device), r1=d[2], r2=d[3], r2_scale=0.5)
+    y, st = ops.bn_act_channel(d[0], bn1, act=act, **kw)
+    (y.float() * go.to(device).float()).sum().backward()
+    tol_f, tol_b = (2e-5, 2e-4) if dtype == "f32" else (1e-2, 3e-2)
+    assert rel_err(y.float().cpu(), u.detach()) < tol_f
+    assert rel_err(bn1.running_mean.cpu(), rm_ref) < 1e-5 and rel_err(bn1.running_var.cpu(), rv_ref) < 1e-4
+    zf = z1.float()
+    assert rel_err(st[0].cpu(), zf.mean((0, 2, 3))) < 1e-5
+    assert rel_err(st[1].cpu(), (zf.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    assert rel_err(d[0].grad.float().cpu(), a.grad) < tol_b
+    assert rel_err(bn1.weight.grad.cpu(), w1.grad) < tol_b and rel_err(bn1.bias.grad.cpu(), c1.grad) < tol_b
+    if two:
+        assert rel_err(bn2.running_var.cpu(), rv2_ref) < 1e-4
+        assert rel_err(d[1].grad.float().cpu(), bb.grad) < tol_b
+        assert rel_err(bn2.weight.grad.cpu(), w2.grad) < tol_b and rel_err(bn2.bias.grad.cpu(), c2.grad) < tol_b
+    if res:
+        assert rel_err(d[2].grad.float().cpu(), q1.grad) < tol_b and rel_err(d[3].grad.float().cpu(), q2.grad) < tol_b

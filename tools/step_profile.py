@@ -62,7 +62,8 @@ def main():
     span = sum(hist.values())
     print("kernels in flight: " + "  ".join(f"{k if k < 3 else '3+'}: {100 * v / span:.1f}%" for k, v in sorted(hist.items())))
     print("top kernels:")
-    for n, (t, c) in sorted(per.items(), key=lambda x: -x[1][0])[:30]:
-        print(f"  {t/1e6/steps:7.2f} ms/step {c//steps:5d}/step avg {t/c/1e3:8.1f} us  {n[:110]}")
+    top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+    for n, (t, c) in sorted(per.items(), key=lambda x: -x[1][0])[:top]:
+        print(f"  {t/1e6/steps:7.2f} ms/step {c//steps:5d}/step avg {t/c/1e3:8.1f} us  {n[:150]}")
 
 main()
