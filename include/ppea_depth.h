@@ -309,6 +309,19 @@ int ppea_conv_wgrad_nhwc_bf16(const void* dz, const void* x, void* dw, int dw_bf
 int ppea_image_to_nhwc_bf16(const float* x, void* y, int N, int C, int H, int W, int Cp, float sub, float div,
                             void* stream);
 
+/* Image-fed convolutions (csrc/conv_image.hip): RepLKNet stem[0] (networks/replknet_adapter.py:411, 3x3 stride 2) and
+ * the pose ResNet-18 conv1 (networks/resnet_encoder.py:376-388, 7x7 stride 2).  The frame is channels-last bf16 with its
+ * 3 / 6 channels zero-padded to 8 (ppea_image_to_nhwc_bf16); one MFMA contraction covers a whole filter ROW (S taps x 8
+ * channels are contiguous in memory), weights packed [K][Cout][K*8 padded to 32].  Forward and weight gradient
+ * (dw [Cout][Cin][K][K], Cin <= 8 real channels); no data gradient (the input is the frame). */
+long ppea_conv_image_packed_bytes(int Cout, int K);
+int ppea_conv_image_pack_weights(const void* w, int w_is_bf16, void* packed, int Cout, int Cin, int K, void* stream);
+int ppea_conv_image_bf16(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cout, int K, int stride,
+                         int pad, int Ho, int Wo, int out_nchw, void* stream);
+long ppea_conv_image_wgrad_workspace_bytes(int N, int Cout, int K, int Ho, int Wo);
+int ppea_conv_image_wgrad_bf16(const void* dz, const void* x, void* dw, int dw_bf16, void* workspace, int N, int H, int W,
+                               int Cin, int Cout, int K, int stride, int pad, int Ho, int Wo, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * A9  match_features (replk_matching_adapter.py:261-340), one lookup frame per item.
  *      cur, lookup [B,C,h,w]; P [B,3,4] = (K @ T)[:, :3, :] at the matching scale;

@@ -1137,11 +1137,68 @@ class _ConvNhwc(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None
 
 
+_IMG_PACK_CACHE = {}
+
+
+def _image_packed(w):
+    Cout, Cin, K, _ = w.shape
+    cacheable = not w.requires_grad
+    key = id(w)
+    hit = _IMG_PACK_CACHE.get(key) if cacheable else None
+    if hit is not None and hit[2]() is w and hit[0] == w._version:
+        return hit[1]
+    wd = w.detach()
+    if wd.dtype not in (_F32, _BF16) or not wd.is_contiguous():
+        wd = wd.float().contiguous()
+    buf = torch.empty(_abi.lib.ppea_conv_image_packed_bytes(Cout, K) // 2, dtype=_BF16, device=w.device)
+    call("ppea_conv_image_pack_weights", ptr(wd), int(wd.dtype == _BF16), ptr(buf), Cout, Cin, K, stream_ptr())
+    if cacheable:
+        _IMG_PACK_CACHE[key] = (w._version, buf, weakref.ref(w, lambda _r, k=key: _IMG_PACK_CACHE.pop(k, None)))
+    return buf
+
+
+class _ConvImage(torch.autograd.Function):
+    """stem[0] / pose conv1 on the row-packed image kernels: x [N,8,H,W] bf16 channels_last frames (3 / 6 real channels),
+    w [Cout,Cin,K,K], stride 2.  Weight gradient only (the input is the frame)."""
+
+    @staticmethod
+    def forward(ctx, x, w, pad, out_nchw):
+        N, _, H, W = x.shape
+        Cout, Cin, K, _ = w.shape
+        Ho, Wo = (H + 2 * pad - K) // 2 + 1, (W + 2 * pad - K) // 2 + 1
+        y = torch.empty(N, Cout, Ho, Wo, device=x.device, dtype=_BF16,
+                        memory_format=torch.contiguous_format if out_nchw else torch.channels_last)
+        call("ppea_conv_image_bf16", _nhwc_raw(x), ptr(_image_packed(w)), _nhwc_raw(y), N, H, W, Cout, K, 2, pad, Ho, Wo,
+             int(out_nchw), stream_ptr())
+        ctx.save_for_backward(x, w)
+        ctx.pad = pad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None
+        N, _, H, W = x.shape
+        Cout, Cin, K, _ = w.shape
+        dz = _as_nhwc(dy.to(_BF16))
+        Ho, Wo = dz.shape[2], dz.shape[3]
+        ws = torch.empty(_abi.lib.ppea_conv_image_wgrad_workspace_bytes(N, Cout, K, Ho, Wo) // 4, device=dz.device, dtype=_F32)
+        gdt = w.dtype if w.dtype in (_BF16, _F32) else _F32
+        dw = torch.empty(Cout, Cin, K, K, device=dz.device, dtype=gdt)
+        call("ppea_conv_image_wgrad_bf16", _raw(dz), _raw(x), ptr(dw), int(gdt == _BF16), ptr(ws), N, H, W, Cin, Cout, K, 2,
+             ctx.pad, Ho, Wo, stream_ptr())
+        return None, dw, None, None
+
+
 def conv2d_nhwc(x, w, bias=None, stride=1, pad=0, reflect=False, act="none", out_nchw=False):
     """Dense conv on the matrix cores.  x [N,Cin,H,W] bf16 (channels_last storage preferred), w [Cout,Cin,R,S] (bf16 or
     fp32 parameter), -> [N,Cout,Ho,Wo] bf16 channels_last (or NCHW-contiguous with out_nchw).  Layers whose output
     channel count is not a multiple of 8 (disp conv: 1, pose head: 12) run zero-padded to the next multiple."""
     Cout = w.shape[0]
+    if (x.shape[1] == 8 and w.shape[1] <= 8 and stride == 2 and w.shape[2] in (3, 7) and w.shape[2] == w.shape[3]
+            and bias is None and act == "none" and not reflect and Cout % 8 == 0 and not x.requires_grad):
+        return _ConvImage.apply(_as_nhwc(x), w, pad, out_nchw)        # stem[0] / pose conv1: one contraction per filter row
     if w.shape[1] < x.shape[1]:                 # image-fed layers: x was zero-padded to 8 channels (image_to_nhwc)
         w = torch.cat([w, w.new_zeros(Cout, x.shape[1] - w.shape[1], *w.shape[2:])], 1)
     if Cout % 8 != 0:
