@@ -37,6 +37,24 @@ VALU_PEAK_TF = 157.3        # fp32 vector peak
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 matrix peak
 
 
+def pmc_traffic(kernel):
+    """(bytes per dispatch, file) for `kernel` from the newest committed profiles/r*_pmc_*.csv, or None."""
+    import csv
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.csv")), reverse=True):
+        fetch = write = None
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if "grid" in r and r.get("kernel", "").startswith(kernel):
+                    if r["counter"] == "FETCH_SIZE":
+                        fetch = float(r["mean_per_dispatch"])
+                    elif r["counter"] == "WRITE_SIZE":
+                        write = float(r["mean_per_dispatch"])
+        if fetch is not None and write is not None:
+            return int((2 * fetch + write) * 1024), os.path.relpath(path, ROOT)
+    return None
+
+
 def cpu_baseline(seconds_budget=40.0, eval_root=None):
     """The oracle's full training step on the host CPU: B=2, 192x640, fp32 (config 1)."""
     import types
@@ -201,11 +219,14 @@ def main():
                              "mfma_peak_tflops": MFMA_BF16_PEAK_TF,
                              "mfma_frac": round(executed / t_k / 1e12 / MFMA_BF16_PEAK_TF, 3)})
                 if B == 12 and C0 == 128:
-                    # HBM-side bytes per launch from the PMC passes committed in profiles/r01_pmc_dwconv_pwconv.csv
-                    # (separate --pmc runs; FETCH_SIZE in KB doubled for 16-byte-per-lane loads on gfx950 as
-                    # MI355X_MICROARCH.md prescribes, WRITE_SIZE in KB as reported)
-                    roof["traffic"] = int((2 * 20401.8 + 51014.6) * 1024)
-                    roof["traffic_note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline; 1.32x the algorithmic bytes (column halo re-reads)"
+                    # HBM-side bytes per launch: parsed from the committed PMC summary (separate rocprofv3 --pmc
+                    # FETCH_SIZE / WRITE_SIZE passes over tools/pmc_target.py, same shape; KB per dispatch;
+                    # FETCH_SIZE doubled for 16-byte-per-lane loads on gfx950 as MI355X_MICROARCH.md prescribes)
+                    pmc = pmc_traffic("dwconv_mfma_kernel<31, 5, 0, 5>")
+                    if pmc is not None:
+                        roof["traffic"] = pmc[0]
+                        roof["traffic_note"] = (f"{pmc[1]}: FETCH_SIZE x2 + WRITE_SIZE per dispatch = "
+                                                f"{pmc[0] / bytes_alg:.2f}x the algorithmic bytes")
             else:
                 roof.update({"name": "dwconv_lk_kernel<float,31,5,...>",
                              "binding_roof": "fp32 vector FMA (AI ~ %d F/B)" % round(useful / bytes_alg),

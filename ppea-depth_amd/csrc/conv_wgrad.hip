@@ -199,12 +199,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
     }
 }
 
-// sum over slabs, write dW in parameter layout [Cout][Cin][R][S] (fp32 or bf16)
-__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ ws, void* __restrict__ dw, int dw_bf16, int slabs, int RS,
-                                         int Cout, int Cin, int CoutP, int CinP) {
+// sum over slabs, write dW in parameter layout [Cout][Cin][R][S] (fp32 or bf16).  64 consecutive (tap, co, ci) elements
+// per workgroup (ci fastest: coalesced slab reads) x 16 slab groups, combined through LDS: small-channel layers have
+// few elements and many slabs, so the sum over slabs has to be parallel as well.
+__global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(const float* __restrict__ ws, void* __restrict__ dw,
+                                                                  int dw_bf16, int slabs, int RS, int Cout, int Cin,
+                                                                  int CoutP, int CinP) {
+    __shared__ float part[16][64];
+    const long total = (long)Cout * Cin * RS;
+    const long i = (long)blockIdx.x * 64 + threadIdx.x;
+    float s = 0.f;
+    int ci = 0, co = 0, tap = 0;
+    if (i < total) {
+        ci = (int)(i % Cin);
+        co = (int)((i / Cin) % Cout);
+        tap = (int)(i / ((long)Cin * Cout));
+        for (int k = threadIdx.y; k < slabs; k += 16) s += ws[(((long)k * RS + tap) * CoutP + co) * CinP + ci];
+    }
+    part[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && i < total) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += part[k][threadIdx.x];
+        const long o = ((long)co * Cin + ci) * RS + tap;
+        if (dw_bf16) reinterpret_cast<uint16_t*>(dw)[o] = f32_to_bf16(v);
+        else reinterpret_cast<float*>(dw)[o] = v;
+    }
+}
+
+// few slabs (large-channel layers: many elements, 1-8 slabs): one thread per element, serial sum
+__global__ void conv_wgrad_reduce_flat_kernel(const float* __restrict__ ws, void* __restrict__ dw, int dw_bf16, int slabs,
+                                              int RS, int Cout, int Cin, int CoutP, int CinP) {
     const long total = (long)Cout * Cin * RS;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        // i enumerates (tap, co, ci) with ci fastest: coalesced workspace reads; the store scatters by R*S
         const int ci = (int)(i % Cin);
         const int co = (int)((i / Cin) % Cout);
         const int tap = (int)(i / ((long)Cin * Cout));
@@ -304,9 +332,14 @@ int ppea_conv_wgrad_nhwc_bf16(const void* dz, const void* x, void* dw, int dw_bf
     int err = launch_status();
     if (err) return err;
     const long total = (long)Cout * Cin * R * S;
-    const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, dw_bf16,
-                       p.slabs, R * S, Cout, Cin, p.CoutP, p.CinP);
+    if (p.slabs >= 16) {
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64, 16), 0, st,
+                           (const float*)workspace, dw, dw_bf16, p.slabs, R * S, Cout, Cin, p.CoutP, p.CinP);
+    } else {
+        const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        hipLaunchKernelGGL(conv_wgrad_reduce_flat_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, dw_bf16,
+                           p.slabs, R * S, Cout, Cin, p.CoutP, p.CinP);
+    }
     return launch_status();
 }
 

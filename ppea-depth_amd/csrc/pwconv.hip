@@ -15,6 +15,8 @@
 //   * global -> register prefetch of the next K-tile overlaps the MFMAs of the current one; LDS is
 //     double buffered so a K step costs one barrier.
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -105,8 +107,8 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
                 if (a_row[c] < BK) {
                     const int s = b_swz(a_row[c]);
                     uint8_t* rowp = As + a_row[c] * B_STRIDE;
-                    *reinterpret_cast<uint2*>(rowp + (((2 * a_ch[c]) ^ s) << 3)) = make_uint2(a_reg[c].x, a_reg[c].y);
-                    *reinterpret_cast<uint2*>(rowp + (((2 * a_ch[c] + 1) ^ s) << 3)) = make_uint2(a_reg[c].z, a_reg[c].w);
+                    // the swizzle is a multiple of 4 chunks: the two 8-byte halves stay adjacent -> one 16-byte store
+                    *reinterpret_cast<uint4*>(rowp + (((2 * a_ch[c]) ^ s) << 3)) = a_reg[c];
                 }
             } else {
                 if (a_row[c] < BM) *reinterpret_cast<uint4*>(As + a_row[c] * A_STRIDE + a_ch[c] * 16) = a_reg[c];
@@ -116,8 +118,7 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
         for (int c = 0; c < B_CH; ++c) {
             const int s = b_swz(b_row[c]);
             uint8_t* rowp = Bs + b_row[c] * B_STRIDE;
-            *reinterpret_cast<uint2*>(rowp + (((2 * b_c16[c]) ^ s) << 3)) = make_uint2(b_reg[c].x, b_reg[c].y);
-            *reinterpret_cast<uint2*>(rowp + (((2 * b_c16[c] + 1) ^ s) << 3)) = make_uint2(b_reg[c].z, b_reg[c].w);
+            *reinterpret_cast<uint4*>(rowp + (((2 * b_c16[c]) ^ s) << 3)) = b_reg[c];
         }
     };
 
@@ -215,6 +216,15 @@ int launch_pw(const void* A, const void* X, const void* bias, int bias_bf16, con
     // 64 channels per step only where it pays (measured): long contraction AND too few tiles to hide the per-step
     // latency by occupancy; with plenty of tiles the smaller LDS footprint (more workgroups per CU) wins.
     const bool deep = K >= 512;
+    static const char* force = getenv("PPEA_PW_TILE");          // tuning hook (tools/bench_pw2.py): "128", "64", "32" [+ "d"]
+    if (force != nullptr) {
+        const int bm = atoi(force);
+        const bool dp = strchr(force, 'd') != nullptr;
+        if (bm == 128) PW_LAUNCH(128, 2, 2, 32);
+        else if (bm == 64) { if (dp) PW_LAUNCH(64, 2, 2, 64); else PW_LAUNCH(64, 2, 2, 32); }
+        else { if (dp) PW_LAUNCH(32, 1, 4, 64); else PW_LAUNCH(32, 1, 4, 32); }
+        return launch_status();
+    }
     if (M >= 128 && blocks128 >= 512) PW_LAUNCH(128, 2, 2, 32);
     else if (M > 32 && blocks64 >= 256) { if (deep) PW_LAUNCH(64, 2, 2, 64); else PW_LAUNCH(64, 2, 2, 32); }
     else { if (deep) PW_LAUNCH(32, 1, 4, 64); else PW_LAUNCH(32, 1, 4, 32); }   // few tiles: smaller workgroups

@@ -26,6 +26,8 @@ _ENC_CH = {"b": [128, 256, 512, 1024], "l": [192, 384, 768, 1536]}
 TWO_STREAMS = True
 BATCHED_POSES = True      # third (no_grad) pose pass replayed instead of recomputed (see _predict_poses_batched)
 POSE_ONE_BATCH = True      # both pairs as one 2B batch with per-pair BN statistics (needs the fused NHWC BN path)
+import os as _os
+POSE_ON_TEACHER_STREAM = _os.environ.get("PPEA_POSE_ON_SIDE", "0") == "1"
 
 
 def _g(opt, name, default):
@@ -234,10 +236,25 @@ class RepDepth(nn.Module):
             side = self._side_stream(img_aug.device)
             side.wait_stream(torch.cuda.current_stream())
         try:
+            pose_pred = None
             if side is not None:
                 with torch.cuda.stream(side):
+                    if POSE_ON_TEACHER_STREAM and not self.freeze_pose:
+                        # the teacher branch is the shorter one: the pose network (forward now, backward at the end of
+                        # the teacher's backward) rides on its stream; the student only waits for the pose of the
+                        # matching frame, which it needs at the cost volume
+                        pose_pred = self.predict_poses(inputs)
+                        pose_ready = torch.cuda.Event()
+                        pose_ready.record(side)
                     mono_outputs.update(self.mono_depth(self.mono_encoder(img_aug)))
-            if not self.freeze_tp and not self.freeze_pose:
+                if pose_pred is not None:
+                    main = torch.cuda.current_stream()
+                    main.wait_event(pose_ready)
+                    for v in list(pose_pred.values()) + [inputs[("relative_pose", i)] for i in self.matching_ids[1:]]:
+                        v.record_stream(main)
+            if pose_pred is not None:
+                pass
+            elif not self.freeze_tp and not self.freeze_pose:
                 pose_pred = self.predict_poses(inputs)
             else:
                 with torch.no_grad():

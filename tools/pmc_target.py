@@ -22,5 +22,13 @@ for (K, H, W, M) in [(512, 12, 40, 512), (2048, 12, 40, 512), (512, 12, 40, 2048
     a = (torch.randn(M, K, device=dev) / K ** 0.5).bfloat16()
     for _ in range(3):
         ops.pwconv_raw(a, xx)
+# dense convs of the decoder on the implicit-GEMM kernels: forward, data gradient, weight gradient
+for (Cin, H, W, Cout) in [(1024, 12, 40, 512), (256, 48, 160, 128), (32, 192, 640, 32)]:
+    xc = torch.randn(B, Cin, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wc = (torch.randn(Cout, Cin, 3, 3, device=dev) / (9 * Cin) ** 0.5).bfloat16().requires_grad_(True)
+    bc = torch.zeros(Cout, device=dev).bfloat16().requires_grad_(True)
+    for _ in range(3):
+        y = ops.conv2d_nhwc(xc, wc, bc, 1, 1, True, "elu")
+        torch.autograd.grad(y, (xc, wc, bc), torch.ones_like(y))
 torch.cuda.synchronize()
 print("done")
