@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ppea-depth_amd"))
 sys.path.insert(0, ROOT)
 
-os.environ.setdefault("MIOPEN_FIND_MODE", "NORMAL")   # full find in warm-up: ~20 % faster steps than FAST
+# (no MIOpen convolutions are left on the step: no find-mode warm-up)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402

@@ -6,7 +6,9 @@ import collections, csv, sys
 def cat(n):
     if 'dwconv' in n: return 'ppea dwconv'
     if '::bn_' in n: return 'ppea bn_fused'
-    if 'conv_nhwc' in n or 'conv_wgrad' in n or 'conv_pack' in n or 'image_to_nhwc' in n: return 'ppea dense conv'
+    if any(k in n for k in ('conv_nhwc', 'conv_wgrad', 'conv_pack', 'image_to_nhwc', 'conv_image', 'image_pack', 'image_wgrad')):
+        return 'ppea dense conv'
+    if 'CatArray' in n: return 'cat'
     if any(k in n for k in ('ssim', 'backproject', 'grid_sample', 'smooth_', 'loss_select', 'cost_volume', 'pack_filter', 'pwconv', 'conv3x3', 'adam_')): return 'ppea other'
     if n.startswith('Cijk'): return 'rocBLAS/hipBLASLt GEMM'
     if 'igemm' in n.lower(): return 'MIOpen igemm'
