@@ -46,6 +46,11 @@ template <> __device__ __forceinline__ void st8<uint16_t>(uint16_t* p, const flo
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// value a store of T would keep (bf16: round to nearest even; fp32: unchanged)
+template <typename T> __device__ __forceinline__ float round_as(float v);
+template <> __device__ __forceinline__ float round_as<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_as<uint16_t>(float v) { return __uint_as_float((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v) << 16); }
+
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
     const int wave = threadIdx.x >> 6;
@@ -598,8 +603,9 @@ template <typename T, bool TWO>
 __global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, const T* __restrict__ z1,
                                                       const T* __restrict__ z2, Branch b1, Branch b2,
                                                       const float* __restrict__ mask, float inv_count,
-                                                      T* __restrict__ dz1, T* __restrict__ dz2,
-                                                      float* __restrict__ sums, int act, int N, int C, int HW) {
+                                                      const T* __restrict__ acc, T* __restrict__ dz1,
+                                                      T* __restrict__ dz2, float* __restrict__ sums, int act, int N,
+                                                      int C, int HW) {
     __shared__ float red[4];
     const int c = blockIdx.x;
     const int hv = HW / V, total = N * hv;
@@ -647,11 +653,16 @@ __global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, 
         if (j >= total) break;
         const int n = j / hv, i = j - n * hv;
         const long off = ((long)n * C + c) * HW + i * V;
-        float e1[V], e2[V];
+        float e1[V], e2[V], ea[V];
+        if (acc != nullptr) ld8<T>(acc + off, ea);         // gradient reaching z1 through its other consumer
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             e1[k] = a1 * (gq[u][k] - mg - (x1[u][k] - mu1) * is1 * m1);
             if constexpr (TWO) e2[k] = a2 * (gq[u][k] - mg - (x2[u][k] - mu2) * is2 * m2);
+        }
+        if (acc != nullptr) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) e1[k] = round_as<T>(e1[k]) + ea[k];   // = the two-kernel result (dz stored, then added)
         }
         st8<T>(dz1 + off, e1);
         if constexpr (TWO) st8<T>(dz2 + off, e2);
@@ -868,16 +879,17 @@ int fwd_channel_impl(const void* z1, const void* z2, const float* const* prm, fl
 }
 template <typename T>
 int bwd_channel_impl(const void* dy, const void* z1, const void* z2, const float* const* st, const float* mask,
-                     float inv_count, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW, void* stream) {
+                     float inv_count, const void* acc, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW,
+                     void* stream) {
     if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS || act < 0 || act > 2)
         return PPEA_ERR_UNSUPPORTED;
     Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
     if (z2 != nullptr)
         hipLaunchKernelGGL((bn_bwd_channel<T, true>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy,
-                           (const T*)z1, (const T*)z2, b1, b2, mask, inv_count, (T*)dz1, (T*)dz2, sums, act, N, C, HW);
+                           (const T*)z1, (const T*)z2, b1, b2, mask, inv_count, (const T*)acc, (T*)dz1, (T*)dz2, sums, act, N, C, HW);
     else
         hipLaunchKernelGGL((bn_bwd_channel<T, false>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy,
-                           (const T*)z1, (const T*)nullptr, b1, b2, mask, inv_count, (T*)dz1, (T*)nullptr, sums, act, N, C, HW);
+                           (const T*)z1, (const T*)nullptr, b1, b2, mask, inv_count, (const T*)acc, (T*)dz1, (T*)nullptr, sums, act, N, C, HW);
     return launch_status();
 }
 
@@ -897,12 +909,14 @@ int ppea_bn_fwd_channel_bf16(const void* z1, const void* z2, const float* const*
     return fwd_channel_impl<uint16_t>(z1, z2, prm, out, eps, momentum, mask, r1, r2, r2_scale, y, act, N, C, HW, stream);
 }
 int ppea_bn_bwd_channel_f32(const void* dy, const void* z1, const void* z2, const float* const* stats, const float* mask,
-                            float inv_count, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW, void* stream) {
-    return bwd_channel_impl<float>(dy, z1, z2, stats, mask, inv_count, dz1, dz2, sums, act, N, C, HW, stream);
+                            float inv_count, const void* acc, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW,
+                            void* stream) {
+    return bwd_channel_impl<float>(dy, z1, z2, stats, mask, inv_count, acc, dz1, dz2, sums, act, N, C, HW, stream);
 }
 int ppea_bn_bwd_channel_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats, const float* mask,
-                             float inv_count, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW, void* stream) {
-    return bwd_channel_impl<uint16_t>(dy, z1, z2, stats, mask, inv_count, dz1, dz2, sums, act, N, C, HW, stream);
+                            float inv_count, const void* acc, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW,
+                            void* stream) {
+    return bwd_channel_impl<uint16_t>(dy, z1, z2, stats, mask, inv_count, acc, dz1, dz2, sums, act, N, C, HW, stream);
 }
 
 // stats[8] = {mean1, invstd1, gamma1, beta1, mean2, invstd2, gamma2, beta2} (branch 2 NULL when z2 is NULL)

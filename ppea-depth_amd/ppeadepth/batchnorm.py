@@ -182,9 +182,11 @@ def assign_groups(model):
     return groups
 
 
-def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None, r2_scale=1.0):
+def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None, r2_scale=1.0, skip=False):
     """act(BN1(z1) [+ BN2(z2)]) [* mask[n]] [+ r1] [+ r2_scale * r2] on the fused HIP kernels
-    (training mode: batch statistics, running stats and checkpoint-replay bookkeeping as BatchNorm2d)."""
+    (training mode: batch statistics, running stats and checkpoint-replay bookkeeping as BatchNorm2d).
+    skip: -> (y, z1'), z1' being z1 for the caller's OTHER use of it (a block's residual connection): where the
+    one-launch kernels serve the shape, the gradient of that use is added inside this BN's backward launch."""
     from . import ops
     assert bn1.training, "fused_bn_act is the training-mode path; eval goes through BatchNorm2d.forward"
     bns = [(z1, bn1)] + ([(z2, bn2)] if z2 is not None else [])
@@ -192,7 +194,12 @@ def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None,
     if (ops.bn_channel_ok(z1) and all(bn.training for _, bn in bns) and not any(bn.sync and _collectives_on() for _, bn in bns)
             and (bn2 is None or (bn2.eps == bn1.eps and bn2.momentum == bn1.momentum))
             and bn1.running_mean.dtype == torch.float32):
-        y, st = ops.bn_act_channel(z1, bn1, z2, bn2, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act)
+        z1_skip = z1
+        if skip and torch.is_grad_enabled() and z1.requires_grad:
+            y, st, z1_skip = ops.bn_act_channel(z1, bn1, z2, bn2, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act,
+                                                skip=True)
+        else:
+            y, st = ops.bn_act_channel(z1, bn1, z2, bn2, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act)
         cnt = float(z1.numel() // z1.shape[1])
         for k, (_, bn) in enumerate(bns):
             if _ACTIVE_DEFERRED is None:
@@ -201,7 +208,7 @@ def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None,
                 _ACTIVE_DEFERRED.count(bn)
                 if bn.replay_update and torch.is_grad_enabled():
                     _ACTIVE_DEFERRED.add(bn, st[2 * k], st[2 * k + 1], cnt)
-        return y
+        return (y, z1_skip) if skip else y
     stats = []
     count, group = None, None
     pre = None
@@ -221,9 +228,10 @@ def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None,
             invstd = torch.rsqrt(bn.running_var.float() + bn.eps)
         stats.append((mean, invstd))
     m2, i2 = (stats[1] if z2 is not None else (None, None))
-    return ops.bn_act_apply(z1, bn1.weight, bn1.bias, stats[0][0], stats[0][1], z2,
-                            None if bn2 is None else bn2.weight, None if bn2 is None else bn2.bias, m2, i2,
-                            mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act, count=count, group=group)
+    y = ops.bn_act_apply(z1, bn1.weight, bn1.bias, stats[0][0], stats[0][1], z2,
+                         None if bn2 is None else bn2.weight, None if bn2 is None else bn2.bias, m2, i2,
+                         mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act, count=count, group=group)
+    return (y, z1) if skip else y
 
 
 class BatchNorm2d(nn.Module):

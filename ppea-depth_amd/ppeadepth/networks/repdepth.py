@@ -18,7 +18,7 @@ from .depth_decoder_v2 import DepthDecoderV2
 from .pose_decoder import PoseDecoder
 from .replk_matching_adapter import RepLKMatchingAdapter
 from .replknet_adapter import create_RepLKNet31B_Adapter, create_RepLKNet31L_Adapter
-from .resnet_encoder import ResnetEncoder
+from .resnet_encoder import ResnetEncoder, replay_updates
 
 _ENC_CH = {"b": [128, 256, 512, 1024], "l": [192, 384, 768, 1536]}
 
@@ -177,8 +177,7 @@ class RepDepth(nn.Module):
             outputs[("cam_T_cam", 0, f_i)] = transformation_from_parameters(aa[:, 0], tt[:, 0], invert=(f_i < 0))
         with torch.no_grad():
             if recorded is not None:                                          # the no_grad pass on pair (-1, 0)
-                for bn, mean, invstd, count in recorded:
-                    bn.replay_update(mean, invstd, count)
+                replay_updates(recorded)
                 self.pose_encoder.recorded = None
             else:
                 self.pose_encoder.replay_pass(stats_a)

@@ -77,9 +77,30 @@ def _drop_mask(drop_path, x):
     """Per-sample DropPath scale [N] (None for Identity / p = 0), drawn where the reference draws it."""
     if not isinstance(drop_path, DropPath) or drop_path.drop_prob == 0.0 or not drop_path.training:
         return None
+    planned = drop_path.__dict__.pop("_planned", None)
+    if planned is not None and planned.shape[0] == x.shape[0]:
+        return planned
     keep = 1.0 - drop_path.drop_prob
     m = rng.bernoulli_keep(x.shape[0], keep, x).reshape(-1).float()
     return m / keep if keep > 0.0 else m
+
+
+def _plan_drop_masks(net, batch, device):
+    """Device-RNG mode: the per-sample DropPath scales of ALL blocks of one encoder pass in two launches (one Bernoulli
+    draw with per-block keep probabilities, one division) instead of three tiny launches per block.  The reference draws
+    block by block from the global generator (timm DropPath); that order only matters to seeded parity runs, which use
+    rng mode "reference" and never come here."""
+    dps = [b.drop_path for st in net.stages for b in st.blocks
+           if isinstance(b.drop_path, DropPath) and b.drop_path.drop_prob > 0.0 and b.drop_path.training]
+    if not dps:
+        return
+    keep = getattr(net, "_keep_probs", None)
+    if keep is None or keep.device != device or keep.shape[0] != len(dps):
+        keep = torch.tensor([1.0 - d.drop_prob for d in dps], dtype=torch.float32, device=device).view(-1, 1)
+        net._keep_probs = keep
+    scales = torch.bernoulli(keep.expand(-1, batch)) / keep          # [blocks, batch]: 0 or 1 / keep
+    for i, d in enumerate(dps):
+        d._planned = scales[i]
 
 
 class LargeKernelDW(nn.Conv2d):
@@ -328,7 +349,7 @@ class ConvFFN(nn.Module):
 
     def forward(self, x):
         if FUSE_BN and self.training and x.is_cuda:
-            out = fused_bn_act(x, self.preffn_bn)
+            out, x = fused_bn_act(x, self.preffn_bn, skip=True)    # x: the same tensor, routed for the residual use
             adpt, join = None, None
             if self.test_id >= 0:
                 if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
@@ -367,7 +388,7 @@ class RepLKBlock(nn.Module):
 
     def forward(self, x):
         if FUSE_BN and self.training and x.is_cuda and hasattr(self.large_kernel, "small_conv"):
-            out = fused_bn_act(x, self.prelkb_bn)
+            out, x = fused_bn_act(x, self.prelkb_bn, skip=True)    # x: the same tensor, routed for the residual use
             adpt, join = None, None
             if self.test_id >= 0:
                 if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
@@ -495,6 +516,8 @@ class RepLKNetAdapter(nn.Module):
         return x
 
     def forward_features(self, x):
+        if FUSE_BN and self.training and x.is_cuda and rng.get_mode() == "device":
+            _plan_drop_masks(self, x.shape[0], x.device)
         x = self.stem_forward(x)
         outs = []
         for s in range(self.num_stages):

@@ -31,7 +31,7 @@ class GroupBN(nn.BatchNorm2d):
                                      and res.is_contiguous(memory_format=torch.channels_last)))):
             y, stats = ops.nhwc_bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, act,
                                        self.groups, self.eps, self.momentum)
-            self.num_batches_tracked += self.groups
+            _count_batches(self, self.groups)
             if self.record is not None:
                 n = (x.shape[0] // self.groups) * x.shape[2] * x.shape[3]
                 for g in range(self.groups):
@@ -63,6 +63,37 @@ class GroupBN(nn.BatchNorm2d):
         self.running_mean.data.lerp_(mean.to(self.running_mean.dtype), self.momentum)
         self.running_var.data.lerp_(var.to(self.running_var.dtype), self.momentum)
         self.num_batches_tracked += 1
+
+
+def _count_batches(bn, n):
+    """num_batches_tracked += n, through the step's deferred multi-tensor update when one is active."""
+    from .. import batchnorm
+    d = batchnorm._ACTIVE_DEFERRED
+    if d is None:
+        bn.num_batches_tracked += n
+    else:
+        d.count(bn, n)
+
+
+def replay_updates(recorded):
+    """`GroupBN.replay_update` for a list of (bn, mean, invstd, count) in a handful of multi-tensor launches (the
+    pose trunk has 20 BNs: 8 tiny launches each otherwise).  Same arithmetic, same order of operations."""
+    if not recorded:
+        return
+    bns = [r[0] for r in recorded]
+    inv = [r[2] for r in recorded]
+    var = torch._foreach_mul(inv, inv)
+    var = torch._foreach_reciprocal(var)
+    torch._foreach_sub_(var, [bn.eps for bn in bns])
+    torch._foreach_mul_(var, [r[3] / max(r[3] - 1, 1) for r in recorded])
+    mom = bns[0].momentum
+    assert all(bn.momentum == mom for bn in bns)
+    torch._foreach_lerp_([bn.running_mean.data for bn in bns],
+                         [r[1].to(bn.running_mean.dtype) for r, bn in zip(recorded, bns)], mom)
+    torch._foreach_lerp_([bn.running_var.data for bn in bns],
+                         [v.to(bn.running_var.dtype) for v, bn in zip(var, bns)], mom)
+    for bn in bns:
+        _count_batches(bn, 1)
 
 
 def _conv(c, x):

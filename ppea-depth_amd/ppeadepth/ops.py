@@ -507,7 +507,8 @@ class _BnActChannel(torch.autograd.Function):
     the saved (mean, invstd) in ONE launch; backward (sums + dz) in one launch."""
 
     @staticmethod
-    def forward(ctx, z1, g1, b1, rm1, rv1, z2, g2, b2, rm2, rv2, mask, r1, r2, r2_scale, act, eps, momentum):
+    def forward(ctx, z1, g1, b1, rm1, rv1, z2, g2, b2, rm2, rv2, mask, r1, r2, r2_scale, act, eps, momentum, skip=False):
+        z1_in = z1
         z1 = z1.contiguous()
         N, C = z1.shape[0], z1.shape[1]
         HW = z1.numel() // (N * C)
@@ -530,10 +531,15 @@ class _BnActChannel(torch.autograd.Function):
         ctx.pdt = (g1.dtype, b1.dtype, None if g2 is None else g2.dtype)
         ctx.mark_non_differentiable(st)
         ctx.set_materialize_grads(False)         # no zero-filled "gradient" of the statistics output per backward call
+        ctx.skip = bool(skip)
+        if skip:
+            # third output: z1 itself, for the block's residual use -- its gradient comes back HERE and is added in the
+            # backward launch (autograd would otherwise add the two gradients of z1 with one more element-wise kernel)
+            return y, st, z1_in
         return y, st
 
     @staticmethod
-    def backward(ctx, dy, _dst):
+    def backward(ctx, dy, _dst, dskip=None):
         z1, z2, st, g1f, b1f, g2f, b2f, maskf = ctx.saved_tensors
         N, C = z1.shape[0], z1.shape[1]
         HW = z1.numel() // (N * C)
@@ -545,23 +551,26 @@ class _BnActChannel(torch.autograd.Function):
         dz2 = None if z2 is None else torch.empty_like(z2)
         stats = _stats_array((st[0], st[1], g1f, b1f, st[2] if z2 is not None else None,
                               st[3] if z2 is not None else None, g2f, b2f))
+        if dskip is not None:
+            dskip = dskip.contiguous().to(z1.dtype)
         call(f"ppea_bn_bwd_channel_{_suffix(z1)}", ptr(dy), ptr(z1), ptr(z2), stats, ptr(maskf), 1.0 / float(N * HW),
-             ptr(dz1), ptr(dz2), ptr(sums), ctx.act, N, C, HW, stream_ptr())
+             ptr(dskip), ptr(dz1), ptr(dz2), ptr(sums), ctx.act, N, C, HW, stream_ptr())
         dg1 = sums[1].to(ctx.pdt[0]) if ctx.needs_input_grad[1] else None
         db1 = sums[0].to(ctx.pdt[1]) if ctx.needs_input_grad[2] else None
         dg2 = sums[2].to(ctx.pdt[2]) if (z2 is not None and ctx.needs_input_grad[6]) else None
         db2 = sums[0].to(ctx.pdt[2]) if (z2 is not None and ctx.needs_input_grad[7]) else None
         dr1 = dy if ctx.has[0] else None
         dr2 = (dy if ctx.r2_scale == 1.0 else dy * ctx.r2_scale) if ctx.has[1] else None
-        return (dz1, dg1, db1, None, None, dz2, dg2, db2, None, None, None, dr1, dr2, None, None, None, None)
+        return (dz1, dg1, db1, None, None, dz2, dg2, db2, None, None, None, dr1, dr2, None, None, None, None, None)
 
 
-def bn_act_channel(z1, bn1, z2=None, bn2=None, mask=None, r1=None, r2=None, r2_scale=1.0, act=ACT_NONE):
-    """-> (y, stats [4,C] = mean1 | invstd1 | mean2 | invstd2).  Updates the running statistics of bn1 / bn2."""
+def bn_act_channel(z1, bn1, z2=None, bn2=None, mask=None, r1=None, r2=None, r2_scale=1.0, act=ACT_NONE, skip=False):
+    """-> (y, stats [4,C] = mean1 | invstd1 | mean2 | invstd2 [, z1 for the residual use when `skip`]).  Updates the
+    running statistics of bn1 / bn2."""
     return _BnActChannel.apply(z1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, z2,
                                None if bn2 is None else bn2.weight, None if bn2 is None else bn2.bias,
                                None if bn2 is None else bn2.running_mean, None if bn2 is None else bn2.running_var,
-                               mask, r1, r2, r2_scale, act, bn1.eps, bn1.momentum)
+                               mask, r1, r2, r2_scale, act, bn1.eps, bn1.momentum, skip)
 
 
 def bn_act_apply(z1, g1, b1, mean1, invstd1, z2=None, g2=None, b2=None, mean2=None, invstd2=None, mask=None,

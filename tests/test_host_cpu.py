@@ -281,8 +281,16 @@ def test_pose_trunk_group_bn_and_pass_replay_cpu():
     one = copy.deepcopy(enc)
     f = one(torch.cat([xa, xb], 0), groups=2, record=True)[-1]
     assert rel_err(f[:2], fa) < 1e-5 and rel_err(f[2:], fb) < 1e-5
+    from ppeadepth.networks.resnet_encoder import replay_updates
+    before = {k: v.clone() for k, v in one.state_dict().items()}
+    with torch.no_grad():
+        replay_updates(one.recorded)                       # the multi-tensor form the step uses
+    many = {k: v.clone() for k, v in one.state_dict().items()}
+    one.load_state_dict(before)
     for bn, mean, invstd, count in one.recorded:
         bn.replay_update(mean, invstd, count)
+    for k, v in one.state_dict().items():
+        assert torch.equal(v, many[k]), k
     # (2) two passes + replay from the running-statistics delta of the first
     two = copy.deepcopy(enc)
     snap = two.snapshot_running()

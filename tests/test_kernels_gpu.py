@@ -867,3 +867,33 @@ def test_bn_channel_one_launch(device, dtype, two, act, res, shape):
         assert rel_err(bn2.weight.grad.cpu(), w2.grad) < tol_b and rel_err(bn2.bias.grad.cpu(), c2.grad) < tol_b
     if res:
         assert rel_err(d[2].grad.float().cpu(), q1.grad) < tol_b and rel_err(d[3].grad.float().cpu(), q2.grad) < tol_b
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_bn_channel_skip_gradient_is_added_in_the_backward_launch(device, dtype):
+    """A block's input feeds its pre-BN AND its residual connection (rka.py:283-289, 315-326).  With `skip=True` the
+    BN returns the input once more for the residual use and adds that use's gradient inside its one backward launch:
+    bit-identical to autograd's separate element-wise add (the BN gradient is rounded to the storage type first, as
+    a stored dz would be), and the autograd graph holds no add node for x."""
+    from ppeadepth import ops
+    from ppeadepth.batchnorm import BatchNorm2d, fused_bn_act
+    shape = (12, 64, 12, 40)
+    g = _g(77)
+    dt = torch.float32 if dtype == "f32" else torch.bfloat16
+    x0 = (torch.randn(shape, generator=g) * 2 + 0.5).to(dt).to(device)
+    go = torch.randn(shape, generator=g).to(dt).to(device)
+    gs = torch.randn(shape, generator=g).to(dt).to(device)
+    grads = []
+    for skip in (False, True):
+        bn = BatchNorm2d(64).to(device)
+        leaf = x0.clone().requires_grad_(True)
+        x = leaf * 1                                           # a non-leaf input, like a block's
+        if skip:
+            y, xs = fused_bn_act(x, bn, skip=True)
+            assert xs.grad_fn is y.grad_fn and xs.data_ptr() == x.data_ptr()
+        else:
+            y, xs = fused_bn_act(x, bn), x
+        ((y * go).sum() + (xs * gs).sum()).backward()
+        grads.append((leaf.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)

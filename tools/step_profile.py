@@ -28,7 +28,7 @@ def main():
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '?'), r.get('Stream_Id', '?')))
     rows.sort()
     adam = [i for i, r in enumerate(rows) if 'FusedOptimizer' in r[2] or 'fused_adam' in r[2].lower() or 'adam_' in r[2]]
     # group consecutive adam launches into step ends
@@ -45,7 +45,7 @@ def main():
     wall = (sel[-1][1] - sel[0][0]) / 1e6 / steps
     agg = collections.defaultdict(lambda: [0.0, 0])
     per = collections.defaultdict(lambda: [0.0, 0])
-    for s, e, n in sel:
+    for s, e, n, *_ in sel:
         agg[cat(n)][0] += (e - s); agg[cat(n)][1] += 1
         per[n][0] += (e - s); per[n][1] += 1
     tot = sum(v[0] for v in agg.values())
@@ -54,7 +54,7 @@ def main():
         print(f"  {k:30s} {t/1e6/steps:8.2f} ms/step {100*t/tot:5.1f}%  {c//steps:6d} launches/step")
     # concurrency: share of the step's wall time with 0 / 1 / 2 / 3+ kernels in flight (parallel graph branches)
     ev = []
-    for st, en, _ in sel:
+    for st, en, *_ in sel:
         ev.append((st, 1)); ev.append((en, -1))
     ev.sort()
     hist, depth, last = collections.defaultdict(float), 0, ev[0][0]
@@ -63,6 +63,14 @@ def main():
         depth += d; last = t
     span = sum(hist.values())
     print("kernels in flight: " + "  ".join(f"{k if k < 3 else '3+'}: {100 * v / span:.1f}%" for k, v in sorted(hist.items())))
+    # per HSA queue / HIP stream: the graph's parallel branches land on different queues; the busiest one bounds the step
+    for col, name in ((3, 'queue'), (4, 'stream')):
+        q = collections.defaultdict(lambda: [0.0, 0, collections.defaultdict(float)])
+        for r in sel:
+            q[r[col]][0] += r[1] - r[0]; q[r[col]][1] += 1; q[r[col]][2][cat(r[2])] += r[1] - r[0]
+        for k, (t, c, cats) in sorted(q.items(), key=lambda x: -x[1][0]):
+            tops = ", ".join(f"{a} {b/1e6/steps:.1f}" for a, b in sorted(cats.items(), key=lambda x: -x[1])[:5])
+            print(f"  {name} {k}: {t/1e6/steps:7.2f} ms/step {c//steps:5d} launches/step  [{tops}]")
     print("top kernels:")
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
     for n, (t, c) in sorted(per.items(), key=lambda x: -x[1][0])[:top]:
