@@ -168,39 +168,51 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    // operands swapped (the two fragment layouts are the same registers): the accumulator holds the
+                    // TRANSPOSED tile -- a lane owns 4 consecutive pixels of one output channel = one 8-byte store
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
         if (more) store_tiles(lds + (cur ^ 1) * BUF);   // the other buffer was last read one barrier ago
         __syncthreads();
         cur ^= 1;
     }
 
-    // epilogue: C layout col = lane & 15 (pixel), row = 4 * (lane >> 4) + r (output channel)
+    // epilogue: transposed C layout -- col = lane & 15 = output channel, row = 4 * (lane >> 4) + r = pixel
+    // (HW % 8 == 0 and the four pixels start at a multiple of 4: all inside the plane or all outside)
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * TM + 16 * i + li;
+        if (m >= M) continue;
+        float bv = 0.f;
+        if (bias != nullptr)
+            bv = bias_bf16 ? bf2f(reinterpret_cast<const uint16_t*>(bias)[m]) : reinterpret_cast<const float*>(bias)[m];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * TM + 16 * i + 4 * g + r;
-            if (m >= M) continue;
-            float bv = 0.f;
-            if (bias != nullptr)
-                bv = bias_bf16 ? bf2f(reinterpret_cast<const uint16_t*>(bias)[m]) : reinterpret_cast<const float*>(bias)[m];
+        for (int j = 0; j < NT; ++j) {
+            const int p = p0 + wn * TN + 16 * j + 4 * g;
+            if (p >= HW) continue;
+            const long o = (long)n * M * HW + (long)m * HW + p;
+            uint16_t v[4];
+            if constexpr (EPI == 0) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int p = p0 + wn * TN + 16 * j + li;
-                if (p >= HW) continue;
-                const long o = (long)n * M * HW + (long)m * HW + p;
-                if constexpr (EPI == 0) {
-                    Y[o] = f2bf(acc[i][j][r] + bv);
-                } else if constexpr (EPI == 1) {
-                    const uint16_t pre = f2bf(acc[i][j][r] + bv);
-                    Y[o] = pre;
-                    Y2[o] = f2bf(gelu_f(bf2f(pre)));
-                } else {
-                    Y[o] = f2bf(acc[i][j][r] * dgelu_f(bf2f(aux[o])));
+                for (int r = 0; r < 4; ++r) v[r] = f2bf(acc[i][j][r] + bv);
+            } else if constexpr (EPI == 1) {
+                uint16_t w[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = f2bf(acc[i][j][r] + bv);
+                    w[r] = f2bf(gelu_f(bf2f(v[r])));
                 }
+                *reinterpret_cast<uint2*>(Y2 + o) = make_uint2(w[0] | ((uint32_t)w[1] << 16), w[2] | ((uint32_t)w[3] << 16));
+            } else {
+                const uint2 a = *reinterpret_cast<const uint2*>(aux + o);
+                const uint16_t x[4] = {(uint16_t)(a.x & 0xffffu), (uint16_t)(a.x >> 16), (uint16_t)(a.y & 0xffffu),
+                                       (uint16_t)(a.y >> 16)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = f2bf(acc[i][j][r] * dgelu_f(bf2f(x[r])));
             }
+            *reinterpret_cast<uint2*>(Y + o) = make_uint2(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16));
         }
+    }
 }
 
 template <int EPI, bool TA>

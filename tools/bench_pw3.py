@@ -1,32 +1,48 @@
 #!/usr/bin/env python3
-"""pwconv per trunk shape: our kernel (dispatch) vs one library GEMM of the same size on a [K][B*HW] matrix
-(the library's best case: no per-image batching, no layout change) -- gives the target for the kernel."""
+"""pwconv per trunk shape, timed as 20 launches inside one hipGraph (no host launch overhead in the number):
+our kernel under the dispatch (or PPEA_PW_TILE=...), optionally (--lib) one library GEMM of the same size on a
+[K][B*HW] matrix (the library's best case: no per-image batching, no layout change)."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "ppea-depth_amd"))
 from ppeadepth import ops
 dev = torch.device("cuda:0")
+REP = 20
 
-def timeit(fn, iters=50):
-    for _ in range(5): fn()
+def graph_time(fn):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(REP): fn()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters): fn()
-    e.record(); torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters * 1e3
+    g.replay(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5): g.replay()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / (5 * REP) * 1e3
 
 shapes = [(12, 128, 48, 160, 128), (12, 128, 48, 160, 512), (12, 512, 48, 160, 128), (12, 256, 24, 80, 256),
           (12, 256, 24, 80, 1024), (12, 1024, 24, 80, 256), (12, 512, 12, 40, 512), (12, 512, 12, 40, 2048),
-          (12, 2048, 12, 40, 512), (12, 1024, 6, 20, 1024), (12, 1024, 6, 20, 4096), (12, 4096, 6, 20, 1024)]
-print("shape                         ours us  TF/s  GB/s | lib us  TF/s | bmm us")
+          (12, 2048, 12, 40, 512), (12, 1024, 6, 20, 1024), (12, 1024, 6, 20, 4096), (12, 4096, 6, 20, 1024),
+          (12, 512, 12, 40, 1152), (12, 512, 12, 40, 128), (12, 128, 12, 40, 512)]
+lib = "--lib" in sys.argv
+tag = os.environ.get("PPEA_PW_TILE", "auto")
+print(f"[{tag}] shape                    ours us  TF/s  GB/s" + (" | lib us  TF/s" if lib else ""))
+tot = 0.0
 for (B, Ci, H, W, Co) in shapes:
     x = torch.randn(B, Ci, H, W, device=dev, dtype=torch.bfloat16)
     w = (torch.randn(Co, Ci, device=dev) / Ci ** 0.5).bfloat16()
-    x2 = torch.randn(Ci, B * H * W, device=dev, dtype=torch.bfloat16)
-    x3 = x.view(B, Ci, H * W)
-    t = timeit(lambda: ops.pwconv_raw(w, x))
-    tl = timeit(lambda: torch.matmul(w, x2))
-    tb = timeit(lambda: torch.matmul(w, x3))
+    t = graph_time(lambda: ops.pwconv_raw(w, x))
+    tot += t
     fl = 2.0 * B * H * W * Ci * Co
     by = 2.0 * (B * H * W * (Ci + Co) + Ci * Co)
-    print(f"{B}x{Ci:4d}x{H:2d}x{W:3d} -> {Co:4d}   {t:7.1f} {fl/t/1e6:6.0f} {by/t/1e3:6.0f} | {tl:6.1f} {fl/tl/1e6:6.0f} | {tb:6.1f}", flush=True)
+    line = f"{B}x{Ci:4d}x{H:2d}x{W:3d} -> {Co:4d}   {t:7.1f} {fl/t/1e6:6.0f} {by/t/1e3:6.0f}"
+    if lib:
+        x2 = torch.randn(Ci, B * H * W, device=dev, dtype=torch.bfloat16)
+        tl = graph_time(lambda: torch.matmul(w, x2))
+        line += f" | {tl:6.1f} {fl/tl/1e6:6.0f}"
+    print(line, flush=True)
+print(f"[{tag}] sum {tot:.1f} us")
