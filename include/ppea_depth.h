@@ -384,6 +384,14 @@ int ppea_bias_elu_fwd_bf16(const void* z, const void* bias, int bias_bf16, void*
 int ppea_bias_elu_bwd_f32(const void* dy, const void* y, void* dz, float* partial, int N, int C, int HW, void* stream);
 int ppea_bias_elu_bwd_bf16(const void* dy, const void* y, void* dz, float* partial, int N, int C, int HW, void* stream);
 
+/* Nearest 2x upsampling fused with the skip concatenation of the depth decoder (networks/depth_decoder_v2.py:231-236;
+ * layers.py:204-207), channels-last: a [N][H/2][W/2][C1], b [N][H][W][C2] (NULL, C2 = 0: no skip) -> out [N][H][W][C1+C2];
+ * backward: dout -> da (2x2 block sums accumulated in fp32), db.  H, W = OUTPUT size (even); C1, C2 % 8 == 0. */
+int ppea_nhwc_up2cat_fwd_f32(const void* a, const void* b, void* out, int N, int H, int W, int C1, int C2, void* stream);
+int ppea_nhwc_up2cat_fwd_bf16(const void* a, const void* b, void* out, int N, int H, int W, int C1, int C2, void* stream);
+int ppea_nhwc_up2cat_bwd_f32(const void* dout, void* da, void* db, int N, int H, int W, int C1, int C2, void* stream);
+int ppea_nhwc_up2cat_bwd_bf16(const void* dout, void* da, void* db, int N, int H, int W, int C1, int C2, void* stream);
+
 /* channels_last versions of the decoder passes (x [B][H][W][C], C % 8 == 0; bias_elu: C / 8 a power of two <= 256):
  * the decoders hand the library's NHWC-native convolutions NHWC activations. */
 int ppea_nhwc_reflect_pad1_fwd_f32(const void* x, void* out, int B, int H, int W, int C, void* stream);

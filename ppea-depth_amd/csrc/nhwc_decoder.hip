@@ -162,6 +162,82 @@ int pad_impl(bool bwd, const void* a, void* o, int B, int H, int W, int C, void*
     return launch_status();
 }
 
+// ---- nearest 2x upsampling fused with the skip concatenation (depth_decoder_v2.py:231-236: upsample(x), then
+// torch.cat with the encoder feature) -- one pass instead of two, 16-byte pieces; and its backward: the gradient of the
+// concatenated tensor is split, the upsampled part summed over each 2x2 block in fp32 (what upsample_nearest2d_backward
+// does) -- one pass instead of slice copies + the library kernel.
+//   out[n][y][x][0:C1] = a[n][y/2][x/2][:]      out[n][y][x][C1:C1+C2] = b[n][y][x][:]        (C2 may be 0)
+template <typename T>
+__global__ __launch_bounds__(TPB) void nhwc_up2cat_fwd(const T* __restrict__ a, const T* __restrict__ b,
+                                                       T* __restrict__ out, int H, int W, int C1, int C2, unsigned total_vec) {
+    const unsigned v = blockIdx.x * TPB + threadIdx.x;
+    if (v >= total_vec) return;
+    const unsigned CT = (unsigned)(C1 + C2) / V;
+    const unsigned pix = v / CT, c0 = (v - pix * CT) * V;
+    const unsigned row = pix / (unsigned)W, x = pix - row * (unsigned)W;
+    const unsigned n = row / (unsigned)H, y = row - n * (unsigned)H;
+    const T* src = (c0 < (unsigned)C1)
+                       ? a + ((long)((n * (unsigned)(H >> 1) + (y >> 1)) * (unsigned)(W >> 1) + (x >> 1))) * C1 + c0
+                       : b + (long)pix * C2 + (c0 - (unsigned)C1);
+    T* dst = out + (long)v * V;
+    reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(src)[0];
+    if (sizeof(T) == 4) reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<const uint4*>(src)[1];
+}
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void nhwc_up2cat_bwd(const T* __restrict__ dout, T* __restrict__ da, T* __restrict__ db,
+                                                       int H, int W, int C1, int C2, unsigned total_a, unsigned total_vec) {
+    const unsigned v = blockIdx.x * TPB + threadIdx.x;
+    if (v >= total_vec) return;
+    const int C = C1 + C2;
+    if (v < total_a) {
+        const unsigned CT = (unsigned)C1 / V, W2 = (unsigned)W >> 1, H2 = (unsigned)H >> 1;
+        const unsigned pix = v / CT, c0 = (v - pix * CT) * V;
+        const unsigned row = pix / W2, x2 = pix - row * W2;
+        const unsigned n = row / H2, y2 = row - n * H2;
+        const T* p = dout + ((long)((n * (unsigned)H + 2 * y2) * (unsigned)W + 2 * x2)) * C + c0;
+        float s[V], t[V];
+        ld8<T>(p, s);
+        ld8<T>(p + C, t);
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] += t[k];
+        ld8<T>(p + (long)W * C, t);
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] += t[k];
+        ld8<T>(p + (long)W * C + C, t);
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] += t[k];
+        st8<T>(da + (long)v * V, s);
+    } else {
+        const unsigned u = v - total_a, CT = (unsigned)C2 / V;
+        const unsigned pix = u / CT, c0 = (u - pix * CT) * V;
+        const T* src = dout + (long)pix * C + C1 + c0;
+        T* dst = db + (long)u * V;
+        reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(src)[0];
+        if (sizeof(T) == 4) reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<const uint4*>(src)[1];
+    }
+}
+
+template <typename T>
+int up2cat_impl(bool bwd, const void* p0, const void* p1, void* p2, int N, int H, int W, int C1, int C2, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || C1 <= 0 || (C1 % V) != 0 || C2 < 0 || (C2 % V) != 0)
+        return PPEA_ERR_UNSUPPORTED;
+    const long pixels = (long)N * H * W;
+    if (pixels * (C1 + C2) > 0x7fffffffL) return PPEA_ERR_UNSUPPORTED;           // 32-bit piece indices
+    if (!bwd) {
+        if (C2 > 0 && p1 == nullptr) return PPEA_ERR_ARG;
+        const unsigned total = (unsigned)(pixels * (C1 + C2) / V);
+        hipLaunchKernelGGL(nhwc_up2cat_fwd<T>, dim3((total + TPB - 1) / TPB), dim3(TPB), 0, (hipStream_t)stream,
+                           (const T*)p0, (const T*)p1, (T*)p2, H, W, C1, C2, total);
+    } else {
+        if (C2 > 0 && p2 == nullptr) return PPEA_ERR_ARG;
+        const unsigned total_a = (unsigned)(pixels / 4 * C1 / V), total = total_a + (unsigned)(pixels * C2 / V);
+        hipLaunchKernelGGL(nhwc_up2cat_bwd<T>, dim3((total + TPB - 1) / TPB), dim3(TPB), 0, (hipStream_t)stream,
+                           (const T*)p0, (T*)p1, (T*)p2, H, W, C1, C2, total_a, total);
+    }
+    return launch_status();
+}
+
 }  // namespace
 
 extern "C" {
@@ -214,6 +290,22 @@ int ppea_nhwc_bias_elu_bwd_bf16(const void* dy, const void* y, void* dz, float* 
     hipLaunchKernelGGL(nhwc_bias_elu_bwd<uint16_t>, dim3(slabs), dim3(TPB), (size_t)(TPB / (C / V)) * C * sizeof(float),
                        (hipStream_t)stream, (const uint16_t*)dy, (const uint16_t*)y, (uint16_t*)dz, partial, P, C, rows);
     return launch_status();
+}
+
+// a [N][H/2][W/2][C1], b [N][H][W][C2] (or NULL with C2 = 0) -> out [N][H][W][C1+C2]: nearest 2x upsampling of a next to b.
+// H, W: the OUTPUT size (even); C1, C2 multiples of 8.
+int ppea_nhwc_up2cat_fwd_f32(const void* a, const void* b, void* out, int N, int H, int W, int C1, int C2, void* stream) {
+    return up2cat_impl<float>(false, a, b, out, N, H, W, C1, C2, stream);
+}
+int ppea_nhwc_up2cat_fwd_bf16(const void* a, const void* b, void* out, int N, int H, int W, int C1, int C2, void* stream) {
+    return up2cat_impl<uint16_t>(false, a, b, out, N, H, W, C1, C2, stream);
+}
+// dout [N][H][W][C1+C2] -> da [N][H/2][W/2][C1] (2x2 block sums, fp32 accumulation), db [N][H][W][C2]
+int ppea_nhwc_up2cat_bwd_f32(const void* dout, void* da, void* db, int N, int H, int W, int C1, int C2, void* stream) {
+    return up2cat_impl<float>(true, dout, da, db, N, H, W, C1, C2, stream);
+}
+int ppea_nhwc_up2cat_bwd_bf16(const void* dout, void* da, void* db, int N, int H, int W, int C1, int C2, void* stream) {
+    return up2cat_impl<uint16_t>(true, dout, da, db, N, H, W, C1, C2, stream);
 }
 
 }  // extern "C"

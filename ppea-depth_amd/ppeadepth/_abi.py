@@ -112,6 +112,10 @@ SIGNATURES = {
     "ppea_conv_nhwc_bf16": [_vp, _vp, _vp, _i, _vp] + [_i] * 15 + [_vp],
     "ppea_conv_wgrad_workspace_bytes": [_i] * 8,
     "ppea_conv_wgrad_nhwc_bf16": [_vp, _vp, _vp, _i, _vp] + [_i] * 12 + [_vp],
+    "ppea_nhwc_up2cat_fwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_up2cat_fwd_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_up2cat_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_up2cat_bwd_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ppea_cost_volume_fwd_f32": [_vp] * 7 + [_i] * 5 + [_f, _vp],
     "ppea_cost_volume_reduce_f32": [_vp] * 6 + [_i] * 4 + [_vp],
 }

@@ -66,6 +66,19 @@ def upsample(x):
     return F.interpolate(x, scale_factor=2, mode="nearest")
 
 
+def upsample_cat(x, skip=None):
+    """depth_decoder_v2.py:231-236: `upsample(x)` followed, where the level has a skip connection, by
+    `torch.cat([x, skip], 1)` -- on channels_last HIP tensors one fused pass (and one fused pass backward)."""
+    if x.is_cuda:
+        from . import ops
+        if skip is not None and skip.dtype != x.dtype:
+            skip = skip.to(x.dtype)
+        if ops.up2cat_supported(x, skip):
+            return ops.upsample2x_cat(x, skip)
+    x = upsample(x)
+    return x if skip is None else torch.cat([x, skip], 1)
+
+
 class Conv3x3(nn.Module):
     """layers.py:119-135 (reflection- or zero-padded 3x3 conv)."""
 

@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..layers import ConvBlock, Conv3x3, upsample
+from ..layers import ConvBlock, Conv3x3, upsample, upsample_cat
 
 
 NHWC = True
@@ -73,11 +73,9 @@ class DepthDecoderV2(nn.Module):
             x_up = F.interpolate(x, scale_factor=8, mode="nearest")
             adpt_out = self.deconv_adpt(self.adapter(torch.cat([input_features[0], x_up], 1)))
         for i in range(4):
-            x = upsample(self.upconvs_0[i](x))
-            if i < 3:
-                x = torch.cat([x, input_features[2 - i]], 1)
+            x = upsample_cat(self.upconvs_0[i](x), input_features[2 - i] if i < 3 else None)
             x = self.upconvs_1[i](x)
-        x = self.upconvs_1[-1](upsample(self.upconvs_0[-1](x)))
+        x = self.upconvs_1[-1](upsample_cat(self.upconvs_0[-1](x)))
         if self.dc:
             x = x + F.interpolate(adpt_out, scale_factor=2)
         self.outputs[("disp", 0)] = self.disp_convs[0](x, act="sigmoid")          # sigmoid in the conv's epilogue

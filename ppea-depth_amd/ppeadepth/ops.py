@@ -1059,6 +1059,49 @@ def _as_nhwc(t):
     return t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
 
 
+# ---------------------------------------------------------------------------------------------
+# decoder glue: nearest 2x upsampling + skip concatenation in one pass (channels_last)
+# ---------------------------------------------------------------------------------------------
+def up2cat_supported(a, b=None):
+    ok = (a.is_cuda and a.dim() == 4 and a.dtype in (_F32, _BF16) and a.shape[1] % 8 == 0
+          and a.is_contiguous(memory_format=torch.channels_last))
+    if ok and b is not None:
+        ok = (b.dtype == a.dtype and b.shape[1] % 8 == 0 and b.shape[0] == a.shape[0]
+              and tuple(b.shape[2:]) == (2 * a.shape[2], 2 * a.shape[3])
+              and b.is_contiguous(memory_format=torch.channels_last))
+    return ok
+
+
+class _Up2Cat(torch.autograd.Function):
+    """cat([interpolate(a, scale_factor=2, mode="nearest"), b], 1) on channels_last tensors in ONE pass; backward
+    splits the gradient and sums the upsampled part over each 2x2 block (fp32 accumulation) in one pass."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        N, C1, h, w = a.shape
+        C2 = 0 if b is None else b.shape[1]
+        out = torch.empty(N, C1 + C2, 2 * h, 2 * w, device=a.device, dtype=a.dtype, memory_format=torch.channels_last)
+        call(f"ppea_nhwc_up2cat_fwd_{_suffix(a)}", _nhwc_raw(a), None if b is None else _nhwc_raw(b), _nhwc_raw(out),
+             N, 2 * h, 2 * w, C1, C2, stream_ptr())
+        ctx.dims = (N, C1, C2, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, C1, C2, h, w = ctx.dims
+        dout = _as_nhwc(dout)
+        da = torch.empty(N, C1, h, w, device=dout.device, dtype=dout.dtype, memory_format=torch.channels_last)
+        db = None if C2 == 0 else torch.empty(N, C2, 2 * h, 2 * w, device=dout.device, dtype=dout.dtype,
+                                              memory_format=torch.channels_last)
+        call(f"ppea_nhwc_up2cat_bwd_{_suffix(dout)}", _nhwc_raw(dout), _nhwc_raw(da), None if db is None else _nhwc_raw(db),
+             N, 2 * h, 2 * w, C1, C2, stream_ptr())
+        return da, db
+
+
+def upsample2x_cat(a, b=None):
+    return _Up2Cat.apply(a, b)
+
+
 def conv_nhwc_raw(x, wp, bias, Cout, R, S, stride, pad, reflect, dil, Ho, Wo, act, out_nchw):
     """One launch of the implicit-GEMM kernel.  x: bf16, channels_last storage, logical [N,Cin,H,W]."""
     N, Cin, H, W = x.shape

@@ -897,3 +897,41 @@ def test_bn_channel_skip_gradient_is_added_in_the_backward_launch(device, dtype)
         grads.append((leaf.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 6, 10, 24), (3, 64, 12, 40, 0), (2, 8, 3, 5, 8)])
+def test_upsample2x_cat_one_pass(device, dtype, shape):
+    """Decoder glue (depth_decoder_v2.py:231-236): nearest 2x upsampling + skip concatenation in one launch, and the
+    split + 2x2 block sum backward in one launch -- exact against F.interpolate / torch.cat and their autograd
+    (copies forward; backward sums four values in fp32 and rounds once, like upsample_nearest2d_backward)."""
+    import torch.nn.functional as F
+    from ppeadepth import ops
+    from ppeadepth.layers import upsample_cat
+    N, C1, h, w, C2 = shape
+    g = _g(N * 1000 + C1 + C2)
+    dt = torch.float32 if dtype == "f32" else torch.bfloat16
+    a0 = torch.randn(N, C1, h, w, generator=g).to(dt).to(device).contiguous(memory_format=torch.channels_last)
+    b0 = None if C2 == 0 else torch.randn(N, C2, 2 * h, 2 * w, generator=g).to(dt).to(device).contiguous(
+        memory_format=torch.channels_last)
+    go = torch.randn(N, C1 + C2, 2 * h, 2 * w, generator=g).to(dt).to(device).contiguous(memory_format=torch.channels_last)
+    res = []
+    for fused in (False, True):
+        a = a0.clone().requires_grad_(True)
+        b = None if b0 is None else b0.clone().requires_grad_(True)
+        if fused:
+            assert ops.up2cat_supported(a, b)
+            y = upsample_cat(a, b)
+            assert y.is_contiguous(memory_format=torch.channels_last)
+        else:
+            y = F.interpolate(a, scale_factor=2, mode="nearest")
+            y = y if b is None else torch.cat([y, b], 1)
+        (y * go).sum().backward()
+        res.append((y.detach(), a.grad, None if b is None else b.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    if dtype == "f32":
+        assert rel_err(res[1][1], res[0][1]) < 1e-6          # summation order inside the 2x2 block
+    else:
+        assert rel_err(res[1][1].float(), res[0][1].float()) < 2 ** -8
+    if C2:
+        assert torch.equal(res[0][2], res[1][2])
