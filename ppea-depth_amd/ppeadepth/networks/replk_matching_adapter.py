@@ -73,6 +73,7 @@ class RepLKMatchingAdapter(nn.Module):
 
     def feature_extraction(self, image, return_all_feats=False):
         """rkm.py:342-369: stem + stage 0."""
+        self.replk.plan_drop_masks(image, stages=(0,))
         x = self.replk.stem_forward(image)
         x = self.replk.stages[0](x)
         return x, [self.replk.stages[0].norm(x)]
@@ -103,6 +104,7 @@ class RepLKMatchingAdapter(nn.Module):
         x = ops.conv_module(self.reduce_conv[0], cat, "relu", out_nchw=True) if cat.is_cuda else None   # bias + ReLU fused
         if x is None:
             x = self.reduce_conv(cat)
+        self.replk.plan_drop_masks(x, stages=range(1, self.replk.num_stages))
         x = self.replk.transitions[0](x)
         for s in range(1, self.replk.num_stages):
             x = self.replk.stages[s](x)

@@ -85,19 +85,21 @@ def _drop_mask(drop_path, x):
     return m / keep if keep > 0.0 else m
 
 
-def _plan_drop_masks(net, batch, device):
+def _plan_drop_masks(net, batch, device, stages=None):
     """Device-RNG mode: the per-sample DropPath scales of ALL blocks of one encoder pass in two launches (one Bernoulli
     draw with per-block keep probabilities, one division) instead of three tiny launches per block.  The reference draws
     block by block from the global generator (timm DropPath); that order only matters to seeded parity runs, which use
     rng mode "reference" and never come here."""
-    dps = [b.drop_path for st in net.stages for b in st.blocks
+    which = tuple(range(len(net.stages))) if stages is None else tuple(stages)
+    dps = [b.drop_path for si in which for b in net.stages[si].blocks
            if isinstance(b.drop_path, DropPath) and b.drop_path.drop_prob > 0.0 and b.drop_path.training]
     if not dps:
         return
-    keep = getattr(net, "_keep_probs", None)
+    cache = net.__dict__.setdefault("_keep_probs", {})
+    keep = cache.get(which)
     if keep is None or keep.device != device or keep.shape[0] != len(dps):
         keep = torch.tensor([1.0 - d.drop_prob for d in dps], dtype=torch.float32, device=device).view(-1, 1)
-        net._keep_probs = keep
+        cache[which] = keep
     scales = torch.bernoulli(keep.expand(-1, batch)) / keep          # [blocks, batch]: 0 or 1 / keep
     for i, d in enumerate(dps):
         d._planned = scales[i]
@@ -515,9 +517,13 @@ class RepLKNetAdapter(nn.Module):
             x = layer(x)
         return x
 
-    def forward_features(self, x):
+    def plan_drop_masks(self, x, stages=None):
+        """Device-RNG training passes: draw the DropPath scales of the given stages (default all) for one pass now."""
         if FUSE_BN and self.training and x.is_cuda and rng.get_mode() == "device":
-            _plan_drop_masks(self, x.shape[0], x.device)
+            _plan_drop_masks(self, x.shape[0], x.device, stages)
+
+    def forward_features(self, x):
+        self.plan_drop_masks(x)
         x = self.stem_forward(x)
         outs = []
         for s in range(self.num_stages):
