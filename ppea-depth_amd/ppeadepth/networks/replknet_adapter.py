@@ -8,6 +8,7 @@ norm is `ppeadepth.batchnorm.BatchNorm2d`, and `use_checkpoint` never recomputes
 (see batchnorm.py).
 """
 import os
+import sys
 
 import torch
 import torch.nn as nn
@@ -502,7 +503,7 @@ class RepLKNetAdapter(nn.Module):
 
     def load_pretrained(self, path):
         if not os.path.exists(path):
-            print(f"[ppeadepth] pretrained backbone {path} not found: keeping random initialisation")
+            print(f"[ppeadepth] pretrained backbone {path} not found: keeping random initialisation", file=sys.stderr)
             return
         weights = torch.load(path, map_location="cpu")
         for key in ("model", "state_dict"):
