@@ -101,7 +101,7 @@ def _plan_drop_masks(net, batch, device, stages=None):
     if keep is None or keep.device != device or keep.shape[0] != len(dps):
         keep = torch.tensor([1.0 - d.drop_prob for d in dps], dtype=torch.float32, device=device).view(-1, 1)
         cache[which] = keep
-    scales = torch.bernoulli(keep.expand(-1, batch)) / keep          # [blocks, batch]: 0 or 1 / keep
+    scales = rng.drop_path_scales(keep, batch)                       # [blocks, batch]: 0 or 1 / keep
     for i, d in enumerate(dps):
         d._planned = scales[i]
 

@@ -93,6 +93,12 @@ def bernoulli_keep(batch: int, keep_prob: float, like: torch.Tensor) -> torch.Te
     return torch.empty(batch, 1, 1, 1, device=like.device, dtype=like.dtype).bernoulli_(keep_prob)
 
 
+def drop_path_scales(keep: torch.Tensor, batch: int) -> torch.Tensor:
+    """Device mode: the DropPath scales (0 or 1 / keep) of several blocks at once -- keep [blocks, 1] on the device ->
+    [blocks, batch], ONE Bernoulli draw with per-block probabilities instead of one tiny launch per block."""
+    return torch.bernoulli(keep.expand(-1, batch)) / keep
+
+
 def randn_like_cpu_order(shape, device) -> torch.Tensor:
     if _MODE == "reference":
         return _host_draw("randn", (tuple(int(d) for d in shape),), device)

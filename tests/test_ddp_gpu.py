@@ -19,8 +19,9 @@ def _patch_rng():
     """Deterministic draws (no DropPath, no matching augmentation, no tie-break noise).  Returns the originals:
     the parent process must restore them, later tests in the same process draw through the same module."""
     from ppeadepth import rng
-    saved = (rng.bernoulli_keep, rng.aug_draws, rng.randn_like_cpu_order)
+    saved = (rng.bernoulli_keep, rng.aug_draws, rng.randn_like_cpu_order, rng.drop_path_scales)
     rng.bernoulli_keep = lambda batch, keep, like: torch.ones(batch, 1, 1, 1, device=like.device, dtype=like.dtype)
+    rng.drop_path_scales = lambda keep, batch: (1.0 / keep).expand(-1, batch)
     rng.aug_draws = lambda batch, device: torch.full((batch,), 0.9, device=device)
     rng.randn_like_cpu_order = lambda shape, device: torch.zeros(shape, device=device)
     return saved
@@ -28,7 +29,7 @@ def _patch_rng():
 
 def _restore_rng(saved):
     from ppeadepth import rng
-    rng.bernoulli_keep, rng.aug_draws, rng.randn_like_cpu_order = saved
+    rng.bernoulli_keep, rng.aug_draws, rng.randn_like_cpu_order, rng.drop_path_scales = saved
 
 
 def _build(batch):
