@@ -214,12 +214,15 @@ int ppea_reflect_pad1_bwd_bf16(const void* dout, void* din, long planes, int H, 
  * A18+A19  BackprojectDepth -> Project3D fused (layers.py:138-199; trainer.py:904-907).
  *     depth [B,1,H,W]; inv_K [B,4,4] (only [:3,:3] read); P [B,3,4] = (K @ T)[:, :3, :];
  *     grid [B,H,W,2] normalised to [-1,1] (x then y); eps added to z (1e-7).
- *     bwd: d_depth [B,1,H,W] overwritten; dP [B,3,4] ACCUMULATED (caller zero-fills).
+ *     bwd: d_depth [B,1,H,W] and dP [B,3,4] overwritten; dP is summed from per-block partials in a caller-owned
+ *     workspace of ppea_backproject_project_bwd_workspace_bytes(B, H, W) bytes in a FIXED order (no float atomics:
+ *     the pose gradient is bitwise reproducible).
  * ---------------------------------------------------------------------------------------- */
 int ppea_backproject_project_fwd_f32(const float* depth, const float* inv_K, const float* P,
                                      float* grid, int B, int H, int W, float eps, void* stream);
+long ppea_backproject_project_bwd_workspace_bytes(int B, int H, int W);
 int ppea_backproject_project_bwd_f32(const float* depth, const float* inv_K, const float* P,
-                                     const float* d_grid, float* d_depth, float* dP,
+                                     const float* d_grid, float* d_depth, float* dP, void* workspace,
                                      int B, int H, int W, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------

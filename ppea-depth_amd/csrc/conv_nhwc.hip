@@ -24,6 +24,7 @@
 // pixels of one channel.  Global loads of step t+1 are in flight under the MFMAs of step t; LDS is double buffered
 // (one barrier per filter row).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -317,6 +318,225 @@ int dispatch_conv(ConvArgs& a, int ks, hipStream_t st) {
     return PPEA_ERR_UNSUPPORTED;
 }
 
+// ---- 3x3 stride-1 convs with few channels: persistent workgroups, weights resident in LDS --------------------------------
+// The 192x640 / 96x320 levels of the depth decoders (32 and 64 channels; layers.py:103-135, dec.py:172-245) are HBM bound:
+// 1.5 M pixels x 64 bytes.  With one tile per workgroup they ran at 1-1.8 TB/s: every tile re-staged the weights row by
+// row (18 KB per 8 KB of input) behind two barriers per filter row, and a tile's load latency was only hidden by the two
+// or three other workgroups of the CU.  Here a workgroup keeps ALL taps of the filter in LDS, walks over tiles of 8 x 16
+// output pixels, and the halo of the NEXT tile is in flight (global -> registers) under the MFMAs and stores of the current
+// one: one barrier per tile, no weight traffic after the first tile.
+// NTC: 16-channel column tiles (Cout <= 16 * NTC); SL: 32-channel input slices (CinP = 32 * SL).
+template <int NTC, int SL>
+__global__ __launch_bounds__(256) void conv3x3_resident_kernel(const ConvArgs a) {
+    constexpr int TR = 8, TC = 16, HALO_W = TC + 2, HALO_PX = (TR + 2) * HALO_W;      // 10 x 18 = 180 pixels
+    constexpr int CO_ROWS = NTC * 16, MT = 2;
+    constexpr int W_BYTES = SL * 9 * CO_ROWS * PITCH, H_BYTES = SL * HALO_PX * PITCH;
+    constexpr int A_CHUNKS = SL * HALO_PX * 4, MAX_A = (A_CHUNKS + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t* ldsW = lds;
+    uint8_t* ldsH = lds + W_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int tiles = a.tiles_x * a.tiles_y * a.N;              // < 2^31 (host check)
+
+    // resident weights: packed [tap][Cout][CinP] -> LDS [slice][tap][CO_ROWS][32 channels], rows >= Cout zero
+    for (int q = tid; q < SL * 9 * CO_ROWS * 4; q += 256) {
+        const int c = q & 3, row = q >> 2;                       // row = (sl * 9 + tap) * CO_ROWS + co
+        const int co = row % CO_ROWS, st = row / CO_ROWS, tap = st % 9, sl = st / 9;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (co < a.Cout) v = *reinterpret_cast<const uint4*>(a.w + ((long)tap * a.Cout + co) * a.CinP + sl * 32 + c * 8);
+        *reinterpret_cast<uint4*>(ldsW + row * PITCH + ((c ^ swz_chunk(co)) << 4)) = v;
+    }
+
+    // Halo prefetch: `buffer_load` through inline asm.  Written as ordinary loads hipcc sinks them into the branch that
+    // stores them to LDS at the END of the tile (no overlap at all); volatile asm keeps them where they are issued.  The
+    // hardware range check supplies the zeros of the padding ring (offset past the tensor), so no load sits under a branch;
+    // the wait is explicit (`halo_wait`) and names the registers, which ties the LDS stores to it.
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    const unsigned long xb = (unsigned long)a.x;
+    const unsigned nbytes = (unsigned)((long)a.N * a.H * a.W * a.Cin * 2);                 // < 2^31: checked by the host
+    i32x4 rs;
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xb & 0xffffffffu));
+    rs[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(xb >> 32));
+    rs[2] = __builtin_amdgcn_readfirstlane((int)nbytes);
+    rs[3] = __builtin_amdgcn_readfirstlane(0x00020000);
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;     // a register type the asm operands accept
+    u32x4 a_reg[MAX_A];
+    auto load_halo = [&](int t) {
+        const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, n = t / (a.tiles_x * a.tiles_y);
+        const int ih0 = ty * TR - a.pad, iw0 = tx * TC - a.pad;
+#pragma unroll
+        for (int k = 0; k < MAX_A; ++k) {
+            const int q = tid + k * 256;
+            unsigned off = 0x80000000u;                          // past every tensor: reads zeros
+            if (q < A_CHUNKS) {
+                const int c = q & 3, rest = q >> 2, px = rest % HALO_PX, sl = rest / HALO_PX;
+                int ih = ih0 + px / HALO_W, iw = iw0 + px % HALO_W;
+                if (a.reflect) {               // beyond the pad ring only masked outputs read: clamp
+                    ih = ih < 0 ? -ih : (ih >= a.H ? 2 * a.H - 2 - ih : ih);
+                    iw = iw < 0 ? -iw : (iw >= a.W ? 2 * a.W - 2 - iw : iw);
+                    ih = ih < 0 ? 0 : (ih >= a.H ? a.H - 1 : ih);
+                    iw = iw < 0 ? 0 : (iw >= a.W ? a.W - 1 : iw);
+                }
+                const int ch = sl * 32 + c * 8;
+                if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W && ch < a.Cin)
+                    off = (unsigned)((((n * a.H + ih) * a.W + iw) * a.Cin + ch) * 2);
+            }
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(a_reg[k]) : "v"(off), "s"(rs));
+        }
+    };
+    auto halo_wait = [&]() {
+        static_assert(MAX_A == 3, "one wait operand per staged 16-byte piece");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_reg[0]), "+v"(a_reg[1]), "+v"(a_reg[2]));
+    };
+    auto store_halo = [&](uint8_t* buf) {
+#pragma unroll
+        for (int k = 0; k < MAX_A; ++k) {
+            const int q = tid + k * 256;
+            if (q < A_CHUNKS) {
+                const int c = q & 3, rest = q >> 2, px = rest % HALO_PX;          // rest = sl * HALO_PX + px
+                *reinterpret_cast<u32x4*>(buf + rest * PITCH + ((c ^ swz_chunk(px)) << 4)) = a_reg[k];
+            }
+        }
+    };
+
+    int a_px[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_px[i] = (wave * MT + i) * HALO_W + li;          // tile row wave * 2 + i, column li
+    const int b_off = li * PITCH + ((g ^ swz_chunk(li)) << 4);
+
+    // bias of this lane's channels (j * 16 + 4 g + e), once
+    float bias_r[NTC][4];
+#pragma unroll
+    for (int j = 0; j < NTC; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = j * 16 + 4 * g + e;
+            bias_r[j][e] = 0.f;
+            if (a.bias != nullptr && co < a.Cout)
+                bias_r[j][e] = a.bias_bf16 ? bf2f(reinterpret_cast<const uint16_t*>(a.bias)[co])
+                                           : reinterpret_cast<const float*>(a.bias)[co];
+        }
+
+    int t = blockIdx.x;
+    load_halo(t);                                              // grid <= tiles
+    halo_wait();
+    store_halo(ldsH);
+    __syncthreads();
+    int cur = 0;
+    for (; t < tiles; t += gridDim.x) {
+        const int tn = t + gridDim.x;
+        if (tn < tiles) load_halo(tn);                         // in flight under this tile's MFMAs and stores
+        const uint8_t* hb = ldsH + cur * H_BYTES;
+        f32x4 acc[MT][NTC];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTC; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3) {
+                    bf16x8 af[MT], bfr[NTC];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const int px = a_px[i] + r * HALO_W + s3;
+                        af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
+                                                               hb + (sl * HALO_PX + px) * PITCH + ((g ^ swz_chunk(px)) << 4)));
+                    }
+#pragma unroll
+                    for (int j = 0; j < NTC; ++j)
+                        bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(
+                                                                ldsW + b_off + (((sl * 9 + r * 3 + s3) * NTC + j) * 16) * PITCH));
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTC; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                }
+        // epilogue: column = li = tile pixel, row = 4 g + e = channel (weights were the A operand)
+        const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, n = t / (a.tiles_x * a.tiles_y);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int oh = ty * TR + wave * MT + i, ow = tx * TC + li;
+            if (oh >= a.Ho || ow >= a.Wo) continue;
+            uint16_t* row = a.y + (((long)n * a.Ho + oh) * a.Wo + ow) * a.Cout;
+#pragma unroll
+            for (int j = 0; j < NTC; ++j) {
+                const int co = j * 16 + 4 * g;
+                if (co >= a.Cout) continue;
+                uint16_t v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float f = acc[i][j][e];
+                    if (co + e < a.Cout) {
+                        f += bias_r[j][e];
+                        switch (a.act) {
+                            case ACT_RELU: f = f > 0.f ? f : 0.f; break;
+                            case ACT_ELU: f = f > 0.f ? f : (__expf(f) - 1.f); break;
+                            case ACT_SIGMOID: f = 1.f / (1.f + __expf(-f)); break;
+                            default: break;
+                        }
+                    }
+                    v[e] = f2bf(f);
+                }
+                if (co + 3 < a.Cout && (a.Cout & 3) == 0) {
+                    *reinterpret_cast<uint2*>(row + co) = make_uint2(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < a.Cout) row[co + e] = v[e];
+                }
+            }
+        }
+        if (tn < tiles) {
+            halo_wait();
+            store_halo(ldsH + (cur ^ 1) * H_BYTES);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+template <int NTC, int SL>
+int launch_resident(ConvArgs a, hipStream_t st) {
+    a.TR = 8; a.TC = 16;
+    a.tiles_x = (a.Wo + 15) / 16; a.tiles_y = (a.Ho + 7) / 8;
+    constexpr size_t smem = (size_t)SL * 9 * NTC * 16 * PITCH + 2 * (size_t)SL * 180 * PITCH;
+    auto kern = conv3x3_resident_kernel<NTC, SL>;
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    const long tiles = (long)a.tiles_x * a.tiles_y * a.N;
+    int per_cu = (int)((160 * 1024) / smem);
+    per_cu = per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);
+    const long grid = tiles < 256L * per_cu ? tiles : 256L * per_cu;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, st, a);
+    return launch_status();
+}
+
+// few channels, many pixels: the persistent kernel (at least ~4 tiles per workgroup slot, else the per-tile kernel)
+bool resident_ok(const ConvArgs& a, int ks, int out_nchw) {
+    const long tiles = (long)((a.Wo + 15) / 16) * ((a.Ho + 7) / 8) * a.N;
+    // 32 input channels only: with 64 (74 KB of weights + 46 KB of halos = one workgroup per CU) the per-tile kernel was
+    // faster (64->64 @96x320: 76 vs 88 us)
+    return ks == 3 && a.stride == 1 && a.dil == 1 && !out_nchw && a.CinP == 32 && a.Cout <= 64 && a.pad <= 2 && tiles >= 2048 &&
+           (long)a.N * a.H * a.W * a.Cin * 2 < (1L << 31);
+}
+
+int dispatch_resident(const ConvArgs& a, hipStream_t st) {
+    switch ((a.Cout + 15) / 16) {
+        case 1: return launch_resident<1, 1>(a, st);
+        case 2: return launch_resident<2, 1>(a, st);
+        case 3: case 4: return launch_resident<4, 1>(a, st);
+    }
+    return PPEA_ERR_UNSUPPORTED;
+}
+
 // weights [Cout][Cin][R][S] (bf16 or fp32) -> packed bf16 [R*S][Cout][CinP]  (flip = 0)
 //                                         -> packed bf16 [R*S][Cin][CoutP] with both taps reversed (flip = 1: dgrad)
 template <typename T>
@@ -403,6 +623,8 @@ int ppea_conv_nhwc_bf16(const void* x, const void* w_packed, const void* bias, i
     a.stride = stride; a.pad = pad; a.reflect = reflect; a.dil = dil; a.Ho = Ho; a.Wo = Wo; a.act = act;
     a.bias_bf16 = bias_bf16;
     hipStream_t st = (hipStream_t)stream;
+    static const bool no_resident = getenv("PPEA_CONV_NO_RESIDENT") != nullptr;        // tuning hook (tools/bench_conv.py)
+    if (!no_resident && resident_ok(a, R, out_nchw)) return dispatch_resident(a, st);
     if (stride == 1) return out_nchw ? dispatch_conv<1, true>(a, R, st) : dispatch_conv<1, false>(a, R, st);
     return out_nchw ? dispatch_conv<2, true>(a, R, st) : dispatch_conv<2, false>(a, R, st);
 }

@@ -58,14 +58,16 @@ __global__ __launch_bounds__(256) void backproject_project_fwd(const float* __re
     reinterpret_cast<float2*>(grid)[(long)b * H * W + i] = o;
 }
 
-// d_depth (per pixel) and dP (12 sums per batch item: wave shuffle reduce -> LDS -> one atomic
-// per block and entry).
+// d_depth (per pixel) and dP (12 sums per batch item: wave shuffle reduce -> LDS -> one partial per block and entry in
+// `partial` [B][blocks][12]; bp_reduce_dP adds them in a fixed order.  Round 1 added the block sums with float atomics:
+// the pose gradient -- and, after a few optimizer steps, the whole pose branch -- then depended on the order in which
+// the 480 blocks of an image happened to finish).
 __global__ __launch_bounds__(256) void backproject_project_bwd(const float* __restrict__ depth,
                                                                const float* __restrict__ inv_K,
                                                                const float* __restrict__ P,
                                                                const float* __restrict__ d_grid,
                                                                float* __restrict__ d_depth,
-                                                               float* __restrict__ dP, int H, int W,
+                                                               float* __restrict__ partial, int H, int W,
                                                                float eps) {
     __shared__ float red[4][12];
     const int b = blockIdx.y;
@@ -107,7 +109,25 @@ __global__ __launch_bounds__(256) void backproject_project_bwd(const float* __re
     __syncthreads();
     if (threadIdx.x < 12) {
         const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        atomicAdd(dP + b * 12 + threadIdx.x, s);
+        partial[((long)b * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = s;
+    }
+}
+
+// dP[b][k] = sum over the image's blocks, always in the same order (one wave per batch item, fixed tree)
+__global__ __launch_bounds__(64) void bp_reduce_dP(const float* __restrict__ partial, float* __restrict__ dP, int blocks) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    for (int i = lane; i < blocks; i += 64) {
+        const float* p = partial + ((long)b * blocks + i) * 12;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[k] += p[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const float s = wave_sum(acc[k]);
+        if (lane == 0) dP[b * 12 + k] = s;
     }
 }
 
@@ -202,14 +222,21 @@ int ppea_backproject_project_fwd_f32(const float* depth, const float* inv_K, con
     return launch_status();
 }
 
+long ppea_backproject_project_bwd_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H < 2 || W < 2) return 0;
+    return (long)B * ((H * W + 255) / 256) * 12 * (long)sizeof(float);
+}
+
 int ppea_backproject_project_bwd_f32(const float* depth, const float* inv_K, const float* P,
-                                     const float* d_grid, float* d_depth, float* dP, int B, int H, int W,
-                                     float eps, void* stream) {
+                                     const float* d_grid, float* d_depth, float* dP, void* workspace, int B, int H,
+                                     int W, float eps, void* stream) {
     if (B < 0 || H < 2 || W < 2) return PPEA_ERR_UNSUPPORTED;
     if (B == 0) return 0;
+    if (workspace == nullptr) return PPEA_ERR_ARG;
     dim3 g((H * W + 255) / 256, B);
     hipLaunchKernelGGL(backproject_project_bwd, g, dim3(256), 0, (hipStream_t)stream, depth, inv_K, P,
-                       d_grid, d_depth, dP, H, W, eps);
+                       d_grid, d_depth, (float*)workspace, H, W, eps);
+    hipLaunchKernelGGL(bp_reduce_dP, dim3(B), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, dP, (int)g.x);
     return launch_status();
 }
 

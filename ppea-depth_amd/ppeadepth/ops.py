@@ -180,9 +180,10 @@ class _BackprojectProject(torch.autograd.Function):
         depth, inv_K, P = ctx.saved_tensors
         B, _, H, W = depth.shape
         d_depth = torch.empty_like(depth)
-        dP = torch.zeros_like(P)
+        dP = torch.empty_like(P)
+        ws = torch.empty(_abi.lib.ppea_backproject_project_bwd_workspace_bytes(B, H, W) // 4, device=depth.device, dtype=_F32)
         call("ppea_backproject_project_bwd_f32", ptr(depth), ptr(inv_K), ptr(P),
-             ptr(d_grid.contiguous().float()), ptr(d_depth), ptr(dP), B, H, W, ctx.eps, stream_ptr())
+             ptr(d_grid.contiguous().float()), ptr(d_depth), ptr(dP), ptr(ws), B, H, W, ctx.eps, stream_ptr())
         return d_depth, None, dP, None
 
 
