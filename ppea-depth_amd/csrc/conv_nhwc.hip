@@ -303,7 +303,9 @@ int dispatch_bn(const ConvArgs& a, hipStream_t st) {
         // 128 channels per workgroup only when that still leaves two waves of workgroups for the 256 CUs
         if (a.Cout > 64 && tiles * ((a.Cout + 127) / 128) >= 512) return launch_conv<128, 2, 2, STRIDE, NCHW, KS>(a, st);
     }
-    if (a.Cout > 32) return launch_conv<64, 2, 2, STRIDE, NCHW, KS>(a, st);
+    // 64 channels per workgroup unless that leaves CUs without one (small maps, e.g. 1024 -> 512 @6x20: 96 workgroups)
+    static const bool no_narrow = getenv("PPEA_CONV_NO_NARROW") != nullptr;           // tuning hook (tools/bench_conv.py)
+    if (a.Cout > 32 && (no_narrow || tiles * ((a.Cout + 63) / 64) >= 256)) return launch_conv<64, 2, 2, STRIDE, NCHW, KS>(a, st);
     return launch_conv<32, 4, 1, STRIDE, NCHW, KS>(a, st);
 }
 
