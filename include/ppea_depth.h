@@ -109,6 +109,15 @@ int ppea_pwconv_bf16(const void* A, const void* X, const float* bias, void* Y, i
  *                         sum_t T[b][t*Ch+m][y+ky-1][x+kx-1] (zero padded), h = GELU(pre).  W % 4 == 0.
  *   ppea_tapsum_bwd_bf16  its adjoint: dT[b][t*Ch+m][y][x] = g[b][m][y-ky+1][x-kx+1].
  * ---------------------------------------------------------------------------------------- */
+/* ppea_pwconv_bf16 + the statistics of the BatchNorm that follows it (conv_bn / conv_bn_relu, replknet_adapter.py:182-197):
+ * stats [M][P][2] fp32 = per output channel (sum, sum of squares) of the stored bf16 values over P disjoint pixel sets,
+ * P = ppea_pwconv_stats_partials(B, M, K, HW); ppea_bn_finalize_sums_f32 turns them into mean / biased var / invstd of
+ * `count` values per channel and updates the running statistics (fp64 totals, fixed order) -- no statistics pass over Y. */
+int ppea_pwconv_stats_partials(int B, int M, int K, int HW);
+int ppea_pwconv_stats_bf16(const void* A, const void* X, const float* bias, void* Y, float* stats, int B, int M, int K,
+                           int HW, void* stream);
+int ppea_bn_finalize_sums_f32(const float* partial, int P, int C, long count, float eps, float momentum, float* mean,
+                              float* var, float* invstd, float* running_mean, float* running_var, void* stream);
 int ppea_pwconv_ex_bf16(const void* A, const void* X, const void* bias, int bias_bf16, int epi, const void* aux,
                         void* Y, void* Y2, int B, int M, int K, int HW, int a_transposed, void* stream);
 long ppea_pwgrad_workspace_bytes(int B, int M, int N, int HW);

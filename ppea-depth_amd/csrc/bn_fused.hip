@@ -121,6 +121,39 @@ __global__ void bn_finalize(const float* __restrict__ partial, int N, int C, int
     }
 }
 
+// Statistics from per-channel partial sums written by the producing GEMM's epilogue (ppea_pwconv_stats_bf16):
+// partial [C][P][2] = (sum, sum of squares) of disjoint pixel sets, channel-major.  One wave per channel reads its P pairs
+// as one contiguous run; the partials are fp32 sums of <= 64 bf16 values, the totals are taken in fp64 (var = E[x^2] -
+// mean^2 without cancellation trouble) in a fixed order.
+__global__ __launch_bounds__(256) void bn_finalize_sums(const float* __restrict__ partial, int P, int C, float count,
+                                                        float eps, float momentum, float* __restrict__ mean_out,
+                                                        float* __restrict__ var_out, float* __restrict__ invstd_out,
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const float2* p = reinterpret_cast<const float2*>(partial) + (long)c * P;
+    double s = 0.0, q = 0.0;
+    for (int i = lane; i < P; i += 64) {
+        const float2 v = p[i];
+        s += (double)v.x; q += (double)v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, WAVE); q += __shfl_xor(q, o, WAVE); }
+    if (lane == 0) {
+        const double mean = s / (double)count;
+        double var = q / (double)count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        mean_out[c] = (float)mean;
+        var_out[c] = (float)var;
+        invstd_out[c] = rsqrtf((float)var + eps);
+        if (running_mean != nullptr) {
+            const float unbiased = (float)(var * (double)count / fmax((double)count - 1.0, 1.0));
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+    }
+}
+
 // SyncBN (several ranks): local statistics in the layout that goes on the wire, packed[2C+1] = mean[C] |
 // biased var[C] | count, and the Chan combine of the gathered [world][2C+1] table (+ running statistics).
 __global__ void bn_finalize_packed(const float* __restrict__ partial, int N, int C, int HW,
@@ -925,6 +958,13 @@ int ppea_bn_stats_f32(const void* z, float* partial, int N, int C, int HW, void*
 }
 int ppea_bn_stats_bf16(const void* z, float* partial, int N, int C, int HW, void* stream) {
     return stats_impl<uint16_t>(z, partial, N, C, HW, stream);
+}
+int ppea_bn_finalize_sums_f32(const float* partial, int P, int C, long count, float eps, float momentum, float* mean,
+                              float* var, float* invstd, float* running_mean, float* running_var, void* stream) {
+    if (P <= 0 || C <= 0 || count <= 0) return PPEA_ERR_ARG;
+    hipLaunchKernelGGL(bn_finalize_sums, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, partial, P, C, (float)count,
+                       eps, momentum, mean, var, invstd, running_mean, running_var);
+    return launch_status();
 }
 int ppea_bn_finalize_f32(const float* partial, int N, int C, int HW, float eps, float momentum, float* mean,
                          float* var, float* invstd, float* running_mean, float* running_var, void* stream) {

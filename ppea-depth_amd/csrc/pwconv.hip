@@ -40,6 +40,8 @@ __device__ __forceinline__ float dgelu_f(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
+// EPI 4: as EPI 0, and per-channel partial sums (sum, sum of squares) of the values AS STORED, per pixel-wave of the
+// workgroup, into (float*)Y2 [M][B * pixel tiles * WN][2] -- the BatchNorm that follows needs no statistics pass.
 // EPI 0: Y = acc + bias.   EPI 1: Y = pre = acc + bias, Y2 = GELU(pre) (pre rounded to bf16 first, like an
 // autocast nn.GELU on the stored tensor).   EPI 2: Y = acc * GELU'(aux[n][m][p]) (data gradient through GELU).
 // TA: the matrix is given transposed, At [K][M] (m contiguous) -- its tile is staged like the X tile and the A
@@ -186,15 +188,20 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
         float bv = 0.f;
         if (bias != nullptr)
             bv = bias_bf16 ? bf2f(reinterpret_cast<const uint16_t*>(bias)[m]) : reinterpret_cast<const float*>(bias)[m];
+        float st_s = 0.f, st_q = 0.f;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int p = p0 + wn * TN + 16 * j + 4 * g;
             if (p >= HW) continue;
             const long o = (long)n * M * HW + (long)m * HW + p;
             uint16_t v[4];
-            if constexpr (EPI == 0) {
+            if constexpr (EPI == 0 || EPI == 4) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = f2bf(acc[i][j][r] + bv);
+                if constexpr (EPI == 4) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float f = bf2f(v[r]); st_s += f; st_q += f * f; }
+                }
             } else if constexpr (EPI == 1) {
                 uint16_t w[4];
 #pragma unroll
@@ -212,7 +219,29 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
             }
             *reinterpret_cast<uint2*>(Y + o) = make_uint2(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16));
         }
+        if constexpr (EPI == 4) {
+            // the four lane groups g hold the other pixels of channel m: fixed-order butterfly, lane group 0 writes
+            st_s += __shfl_xor(st_s, 16, WAVE); st_q += __shfl_xor(st_q, 16, WAVE);
+            st_s += __shfl_xor(st_s, 32, WAVE); st_q += __shfl_xor(st_q, 32, WAVE);
+            if (g == 0) {
+                // channel-major [M][P][2]: the finalize kernel reads a channel's P partials as one contiguous run
+                const long P = (long)gridDim.z * gridDim.x * WN;
+                float* sp = reinterpret_cast<float*>(Y2) + ((long)m * P + ((long)n * gridDim.x + blockIdx.x) * WN + wn) * 2;
+                sp[0] = st_s; sp[1] = st_q;
+            }
+        }
     }
+}
+
+// tile choice of the dispatch below as (rows per workgroup, waves along the pixels): the statistics epilogue writes one
+// partial per pixel-wave, and the caller sizes / reduces that buffer
+void pw_config(int B, int M, int K, int HW, int& bm, int& wn) {
+    const int nb = (HW + BN - 1) / BN;
+    const long blocks128 = (long)nb * ((M + 127) / 128) * B, blocks64 = (long)nb * ((M + 63) / 64) * B;
+    static const char* force = getenv("PPEA_PW_TILE");
+    if (force != nullptr) bm = atoi(force) == 128 ? 128 : (atoi(force) == 64 ? 64 : 32);
+    else bm = (M >= 128 && blocks128 >= 512) ? 128 : ((M > 32 && blocks64 >= 256) ? 64 : 32);
+    wn = bm == 32 ? 4 : 2;
 }
 
 template <int EPI, bool TA>
@@ -255,6 +284,23 @@ int ppea_pwconv_bf16(const void* A, const void* X, const float* bias, void* Y, i
     if (B <= 0 || M <= 0 || K <= 0 || HW <= 0 || (K % 32) != 0 || (HW % 8) != 0 || B > 65535)
         return PPEA_ERR_UNSUPPORTED;
     return launch_pw<0, false>(A, X, bias, 0, nullptr, Y, nullptr, B, M, K, HW, (hipStream_t)stream);
+}
+
+// ppea_pwconv_bf16 plus the statistics of the BatchNorm that follows (conv_bn / conv_bn_relu, rka.py:182-197): per output
+// channel the sum and the sum of squares of the stored bf16 values, as P = ppea_pwconv_stats_partials(B, M, K, HW) partial
+// pairs, stats [M][P][2] fp32 (every entry written; reduce with ppea_bn_finalize_sums_f32).
+int ppea_pwconv_stats_partials(int B, int M, int K, int HW) {
+    if (B <= 0 || M <= 0 || K <= 0 || HW <= 0) return 0;
+    int bm, wn;
+    pw_config(B, M, K, HW, bm, wn);
+    return B * ((HW + BN - 1) / BN) * wn;
+}
+int ppea_pwconv_stats_bf16(const void* A, const void* X, const float* bias, void* Y, float* stats, int B, int M, int K,
+                           int HW, void* stream) {
+    if (B <= 0 || M <= 0 || K <= 0 || HW <= 0 || (K % 32) != 0 || (HW % 8) != 0 || B > 65535)
+        return PPEA_ERR_UNSUPPORTED;
+    if (stats == nullptr) return PPEA_ERR_ARG;
+    return launch_pw<4, false>(A, X, bias, 0, nullptr, Y, stats, B, M, K, HW, (hipStream_t)stream);
 }
 
 // Same GEMM with an epilogue (adapters, replknet_adapter.py:20-109): epi 0 plain; epi 1 writes the

@@ -117,6 +117,9 @@ SIGNATURES = {
     "ppea_nhwc_up2cat_fwd_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ppea_nhwc_up2cat_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ppea_nhwc_up2cat_bwd_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ppea_pwconv_stats_partials": [_i] * 4,
+    "ppea_pwconv_stats_bf16": [_vp] * 5 + [_i] * 4 + [_vp],
+    "ppea_bn_finalize_sums_f32": [_vp, _i, _i, ctypes.c_long, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "ppea_cost_volume_fwd_f32": [_vp] * 7 + [_i] * 5 + [_f, _vp],
     "ppea_cost_volume_reduce_f32": [_vp] * 6 + [_i] * 4 + [_vp],
 }

@@ -114,7 +114,7 @@ class _SyncBNFn(torch.autograd.Function):
         return dx, gw, gb, None, None, None, None, None
 
 
-def _global_stats(bn, z):
+def _global_stats(bn, z, sums=None):
     """Batch statistics of z for `bn` in training mode: (mean, invstd, count, group).  One rank: two fused
     launches (running stats updated in the second).  Several ranks (sync BN): local stats -> one packed
     all-gather -> Chan combine; running stats updated with the global statistics."""
@@ -122,7 +122,11 @@ def _global_stats(bn, z):
     multi = bn.sync and _collectives_on()
     cnt = z.numel() // z.shape[1]
     if not multi:
-        mean, _var, invstd = ops.bn_batch_stats(z, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
+        if sums is not None and bn.running_mean.dtype == torch.float32:
+            mean, _var, invstd = ops.bn_batch_stats_from_sums(sums, cnt, bn.eps, bn.momentum, bn.running_mean,
+                                                              bn.running_var)
+        else:
+            mean, _var, invstd = ops.bn_batch_stats(z, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
         return mean, invstd, float(cnt), None
     # several ranks: stats + packed finalize (2 launches) -> ONE all-gather -> combine (1 launch)
     group = getattr(bn, "group", None)
@@ -182,9 +186,11 @@ def assign_groups(model):
     return groups
 
 
-def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None, r2_scale=1.0, skip=False):
+def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None, r2_scale=1.0, skip=False, sums=None):
     """act(BN1(z1) [+ BN2(z2)]) [* mask[n]] [+ r1] [+ r2_scale * r2] on the fused HIP kernels
     (training mode: batch statistics, running stats and checkpoint-replay bookkeeping as BatchNorm2d).
+    sums: partial (sum, sum of squares) of z1 per channel from the GEMM that produced it (ops.pwconv_frozen(...,
+    want_sums=True)): the statistics pass over z1 is skipped where it would be a separate launch.
     skip: -> (y, z1'), z1' being z1 for the caller's OTHER use of it (a block's residual connection): where the
     one-launch kernels serve the shape, the gradient of that use is added inside this BN's backward launch."""
     from . import ops
@@ -216,7 +222,7 @@ def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None,
         pre = list(_global_stats_pair(bn1, z1, bn2, z2))
     for z, bn in bns:
         if bn.training:
-            mean, invstd, count, group = pre.pop(0) if pre is not None else _global_stats(bn, z)
+            mean, invstd, count, group = pre.pop(0) if pre is not None else _global_stats(bn, z, sums if z is z1 else None)
             if _ACTIVE_DEFERRED is None:
                 bn.num_batches_tracked += 1
             else:

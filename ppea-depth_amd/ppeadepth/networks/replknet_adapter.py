@@ -149,8 +149,20 @@ class PointwiseConv(nn.Conv2d):
                 return y
         return super().forward(x)
 
+    def forward_sums(self, x):
+        """-> (conv(x), sums or None): on the MFMA path, for activations whose BatchNorm takes separate statistics and
+        apply launches (N * HW > 16 384: stages 0 / 1), the GEMM's epilogue also returns the per-channel partial sums
+        that BatchNorm needs (`fused_bn_act(..., sums=sums)`)."""
+        if (PW_MFMA and BN_SUMS and x.is_cuda and x.dtype == torch.bfloat16 and not self.weight.requires_grad
+                and x.shape[0] * x.shape[2] * x.shape[3] > 16384):
+            r = ops.pwconv_frozen(x, self.weight, want_sums=True)
+            if r is not None:
+                return r
+        return self.forward(x), None
+
 
 PW_MFMA = True
+BN_SUMS = os.environ.get("PPEA_BN_SUMS", "1") == "1"   # BatchNorm statistics from the 1x1 conv's epilogue (stages 0 / 1)
 ADAPTER_MFMA = True    # adapters (forward + every gradient) on the NCHW MFMA kernels under bf16
 
 
@@ -177,6 +189,9 @@ class ConvBNAct(nn.Sequential):
         if not (FUSE_BN and self.training and x.is_cuda):
             return super().forward(x)
         act = ops.ACT_RELU if hasattr(self, "nonlinear") else ops.ACT_NONE
+        if isinstance(self.conv, PointwiseConv):
+            z, sums = self.conv.forward_sums(x)
+            return fused_bn_act(z, self.bn, act=act, sums=sums)
         return fused_bn_act(self.conv(x), self.bn, act=act)
 
 
@@ -335,6 +350,11 @@ class ReparamLargeKernelConv(nn.Module):
             del self.small_conv
 
 
+def _conv_sums(conv, x):
+    """(conv(x), partial sums for the BatchNorm that follows or None)."""
+    return conv.forward_sums(x) if isinstance(conv, PointwiseConv) else (conv(x), None)
+
+
 class ConvFFN(nn.Module):
     """rka.py:264-289."""
 
@@ -359,12 +379,13 @@ class ConvFFN(nn.Module):
                     adpt, join = _forked_adapter(self.mlp_adapter, out)
                 else:
                     adpt = self.mlp_adapter(out)
-            h = fused_bn_act(self.pw1.conv(out), self.pw1.bn, act=ops.ACT_GELU)
-            z = self.pw2.conv(h)
+            z1, s1 = _conv_sums(self.pw1.conv, out)
+            h = fused_bn_act(z1, self.pw1.bn, act=ops.ACT_GELU, sums=s1)
+            z, s2 = _conv_sums(self.pw2.conv, h)
             if join is not None:
                 join()
             return fused_bn_act(z, self.pw2.bn, mask=_drop_mask(self.drop_path, x), r1=x, r2=adpt,
-                                r2_scale=self.gamma)
+                                r2_scale=self.gamma, sums=s2)
         out = self.preffn_bn(x)
         adpt = self.mlp_adapter(out) if self.test_id >= 0 else None
         out = self.pw2(self.nonlinear(self.pw1(out)))
@@ -399,11 +420,11 @@ class RepLKBlock(nn.Module):
                 else:
                     adpt = self.adapter(out)
             t = self.large_kernel.forward_act(self.pw1(out), ops.ACT_RELU)
-            z = self.pw2.conv(t)
+            z, s2 = _conv_sums(self.pw2.conv, t)
             if join is not None:
                 join()
             return fused_bn_act(z, self.pw2.bn, mask=_drop_mask(self.drop_path, x), r1=x, r2=adpt,
-                                r2_scale=self.gamma)
+                                r2_scale=self.gamma, sums=s2)
         out = self.prelkb_bn(x)
         adpt = self.adapter(out) if self.test_id >= 0 else None
         out = self.pw2(self.lk_nonlinear(self.large_kernel(self.pw1(out))))

@@ -398,6 +398,16 @@ def bn_batch_stats(z, eps, momentum, running_mean=None, running_var=None):
     return out[0], out[1], out[2]
 
 
+def bn_batch_stats_from_sums(sums, count, eps, momentum, running_mean=None, running_var=None):
+    """(mean, biased var, invstd) from the producing GEMM's partial sums [C, P, 2] (pwconv_frozen(..., want_sums=True)):
+    one small launch instead of a statistics pass over the activation; updates the running statistics."""
+    C, P = sums.shape[0], sums.shape[1]
+    out = torch.empty(3, C, device=sums.device, dtype=_F32)
+    call("ppea_bn_finalize_sums_f32", ptr(sums, _F32), P, C, int(count), float(eps), float(momentum), ptr(out[0]), ptr(out[1]),
+         ptr(out[2]), ptr(running_mean), ptr(running_var), stream_ptr())
+    return out[0], out[1], out[2]
+
+
 def bn_local_stats_packed(z):
     """SyncBN wire format of the local statistics: [mean(C) | biased var(C) | count] fp32."""
     z = z.contiguous()
@@ -836,24 +846,39 @@ def pwconv_raw(a_mat, x, bias=None):
 
 class _PwConvFrozen(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, want_sums=False):
         a, at = _pw_matrices(w)
-        y = pwconv_raw(a, x.contiguous())
         ctx.at = at
-        return y
+        x = x.contiguous()
+        if not want_sums:
+            return pwconv_raw(a, x)
+        # the epilogue also leaves per-channel partial sums of the stored output: the BatchNorm that follows needs no
+        # statistics pass (batchnorm.fused_bn_act(..., sums=...))
+        B, K, H, W = x.shape
+        M = a.shape[0]
+        y = torch.empty(B, M, H, W, device=x.device, dtype=_BF16)
+        P = _abi.lib.ppea_pwconv_stats_partials(B, M, K, H * W)
+        sums = torch.empty(M, P, 2, device=x.device, dtype=_F32)
+        call("ppea_pwconv_stats_bf16", ptr(a, _BF16), ptr(x, _BF16), None, ptr(y), ptr(sums), B, M, K, H * W, stream_ptr())
+        ctx.mark_non_differentiable(sums)
+        ctx.set_materialize_grads(False)
+        return y, sums
 
     @staticmethod
-    def backward(ctx, dy):
-        return pwconv_raw(ctx.at, dy.contiguous().to(_BF16)), None
+    def backward(ctx, dy, _dsums=None):
+        return pwconv_raw(ctx.at, dy.contiguous().to(_BF16)), None, None
 
 
-def pwconv_frozen(x, w):
+def pwconv_frozen(x, w, want_sums=False):
     """1x1 conv with a frozen weight [Cout,Cin,1,1] on the MFMA kernel; None when the shape is not served
-    (caller falls back to the library conv)."""
+    (caller falls back to the library conv).  want_sums: -> (y, sums [Cout, P, 2]) with the per-channel partial
+    (sum, sum of squares) of y for the BatchNorm that follows."""
     B, K, H, W = x.shape
     if (x.dtype != _BF16 or not x.is_cuda or K % 32 != 0 or w.shape[0] % 32 != 0 or (H * W) % 8 != 0
             or w.requires_grad):
         return None
+    if want_sums:
+        return _PwConvFrozen.apply(x, w, True)
     return _PwConvFrozen.apply(x, w)
 
 

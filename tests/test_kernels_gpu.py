@@ -969,3 +969,29 @@ def test_upsample2x_cat_one_pass(device, dtype, shape):
         assert rel_err(res[1][1].float(), res[0][1].float()) < 2 ** -8
     if C2:
         assert torch.equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("shape", [(12, 128, 48, 160, 512), (3, 256, 24, 88, 96), (2, 64, 40, 72, 32), (12, 512, 48, 160, 128)])
+def test_pwconv_epilogue_sums_give_the_batchnorm_statistics(device, shape):
+    """BatchNorm statistics from the producing 1x1 conv's epilogue (conv_bn / conv_bn_relu, rka.py:182-197): same output
+    bytes as the plain launch; per-channel (sum, sum of squares) partials whose fp64 totals give mean / biased variance /
+    invstd of the STORED bf16 tensor to 1e-6 relative, and the running statistics F.batch_norm would leave (ragged last
+    pixel tile, channel counts that do not fill a workgroup tile, all three tile configurations)."""
+    import torch.nn.functional as F
+    from ppeadepth import ops
+    B, K, H, W, M = shape
+    g = _g(B * 10 + M)
+    x = torch.randn(B, K, H, W, generator=g).bfloat16().to(device)
+    w = (torch.randn(M, K, 1, 1, generator=g) / K ** 0.5 + 0.02).bfloat16().to(device)
+    y0 = ops.pwconv_frozen(x, w)
+    y, sums = ops.pwconv_frozen(x, w, want_sums=True)
+    assert torch.equal(y, y0) and sums.shape[0] == M and sums.shape[2] == 2 and torch.isfinite(sums).all()
+    rm, rv = torch.zeros(M, device=device), torch.ones(M, device=device)
+    mean, var, invstd = ops.bn_batch_stats_from_sums(sums, B * H * W, 1e-5, 0.1, rm, rv)
+    yf = y.float()
+    rm_ref, rv_ref = torch.zeros(M, device=device), torch.ones(M, device=device)
+    F.batch_norm(yf, rm_ref, rv_ref, None, None, True, 0.1, 1e-5)
+    want_mean, want_var = yf.double().mean((0, 2, 3)), yf.double().var((0, 2, 3), unbiased=False)
+    assert rel_err(mean.cpu(), want_mean.cpu()) < 1e-6 and rel_err(var.cpu(), want_var.cpu()) < 1e-5
+    assert rel_err(invstd.cpu(), (want_var + 1e-5).rsqrt().cpu()) < 1e-5
+    assert rel_err(rm.cpu(), rm_ref.cpu()) < 1e-5 and rel_err(rv.cpu(), rv_ref.cpu()) < 1e-5
