@@ -65,6 +65,13 @@ int ppea_dwconv_lk_pack_bf16(const float* w, void* packed, int C, int K, int fli
 int ppea_dwconv_lk_fwd_bf16p(const uint16_t* x, const void* packed_big, const void* packed_small,
                              uint16_t* y_big, uint16_t* y_small,
                              int N, int C, int H, int W, int K, int KS, void* stream);
+/* forward + the statistics of the two BatchNorms that follow the re-parameterised pair (replknet_adapter.py:232-239):
+ * stats [2][C][P][2] fp32, P = ppea_dwconv_lk_stats_partials(...) partial (sum, sum of squares) pairs per channel of the
+ * stored y_big (first half) / y_small values; reduce each half with ppea_bn_finalize_sums_f32. */
+int ppea_dwconv_lk_stats_partials(int N, int C, int H, int W, int K, int KS);
+int ppea_dwconv_lk_fwd_stats_bf16p(const uint16_t* x, const void* packed_big, const void* packed_small, uint16_t* y_big,
+                                   uint16_t* y_small, float* stats, int N, int C, int H, int W, int K, int KS,
+                                   void* stream);
 int ppea_dwconv_lk_bwd_data_bf16p(const uint16_t* dy_big, const uint16_t* dy_small,
                                   const void* packed_big_flip, const void* packed_small_flip,
                                   uint16_t* dx, int N, int C, int H, int W, int K, int KS, void* stream);

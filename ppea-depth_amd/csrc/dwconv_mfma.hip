@@ -366,6 +366,19 @@ __device__ __forceinline__ void store_tile(uint16_t* __restrict__ dst, const f32
     }
 }
 
+// Statistics of what store_tile writes (the values AS STORED: rounded to bf16), for the BatchNorm that follows the conv.
+__device__ __forceinline__ void tile_stats(const f32x4& acc, const RowOffs& ro, int W, int xt, int lane, float& s, float& q) {
+    const int col = xt + 4 * (lane >> 4);
+    if (ro.off < 0) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (col + i < W) {
+            const float v = __uint_as_float((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)acc[i]) << 16);
+            s += v;
+            q += v * v;
+        }
+}
+
 // MODE 0: fwd  (in0 = x; out0 = y_big, out1 = y_small if KS)
 // MODE 1: dgrad (in0 = dy_big, in1 = dy_small if KS; out0 = dx), filters flipped
 template <int K, int KS, int MODE, int NSEG>
@@ -373,7 +386,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     const uint16_t* __restrict__ in0, const uint16_t* __restrict__ in1, const uint16_t* __restrict__ w_big,
     const uint16_t* __restrict__ w_small, uint16_t* __restrict__ out0, uint16_t* __restrict__ out1, int N, int C,
     int H, int W, int G, int band, int bands, int segs, int items_per_channel, int ipw, int wpc,
-    long total_waves, int tile_bytes, int region_bytes) {
+    long total_waves, int tile_bytes, int region_bytes, float* __restrict__ stats) {
     using GE = Geo<K>;
     using GS = Geo<(KS > 0 ? KS : 5)>;
     constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
@@ -441,6 +454,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
         }
         return true;
     };
+    // MODE 0 with `stats`: per-channel partial sums (sum, sum of squares) of both outputs, one entry per wave of the
+    // channel -- stats [2][C][wpc][2] -- so that the BatchNorm pair after the conv needs no statistics pass
+    float st_sb = 0.f, st_qb = 0.f, st_ss = 0.f, st_qs = 0.f;
     int done = 0;
     Item it;
     bool have = make_item(first_item, it);
@@ -512,6 +528,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
             const f32x4 acc = accb[0] + accb[1];
             store_tile(out0, acc, ro, W, it.x0 + nt * 16, lane);
             if constexpr (MODE == 0 && KS > 0) store_tile(out1, accs, ro, W, it.x0 + nt * 16, lane);
+            if constexpr (MODE == 0) {
+                if (stats != nullptr) {                      // wave-uniform
+                    tile_stats(acc, ro, W, it.x0 + nt * 16, lane, st_sb, st_qb);
+                    if constexpr (KS > 0) tile_stats(accs, ro, W, it.x0 + nt * 16, lane, st_ss, st_qs);
+                }
+            }
             if (mt2 != mt && !last) ro = row_offsets(it, C, c, H, W, mt2, lane);
             mt = mt2; nt = nt2; tc = tn;
             PROF_T(t_epi);
@@ -528,6 +550,16 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
         it = nxt;
         have = have_next;
     }
+    if constexpr (MODE == 0) {
+        if (stats != nullptr) {
+            const float sb = wave_sum(st_sb), qb = wave_sum(st_qb), ss = wave_sum(st_ss), qs = wave_sum(st_qs);
+            if (lane == 0) {
+                const long e = ((long)c * wpc + (wid - (long)c * wpc)) * 2;
+                stats[e] = sb; stats[e + 1] = qb;
+                if constexpr (KS > 0) { stats[(long)C * wpc * 2 + e] = ss; stats[(long)C * wpc * 2 + e + 1] = qs; }
+            }
+        }
+    }
 #ifdef DW_PROF
     PROF_T(t_end);
     prof[5] = t_end - t_begin;
@@ -536,9 +568,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
 #endif
 }
 
+// stats / wpc_out: forward only -- per-wave partial sums for the BatchNorm pair (see the kernel); wpc_out != nullptr:
+// do not launch, return the number of waves per channel (= partials per channel) the launch would use
 template <int K, int KS, int MODE, int NSEG>
 int launch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0,
-           uint16_t* o1, int N, int C, int H, int W, hipStream_t st) {
+           uint16_t* o1, int N, int C, int H, int W, hipStream_t st, float* stats = nullptr, int* wpc_out = nullptr) {
     constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
     constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
     constexpr int FILT_BYTES = (packed_elems(K) + (KS > 0 ? packed_elems(KS) : 0)) * 2;
@@ -569,6 +603,7 @@ int launch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const u
     if (wpc > items_per_channel) wpc = items_per_channel;
     const int ipw = (items_per_channel + wpc - 1) / wpc;
     wpc = (items_per_channel + ipw - 1) / ipw;
+    if (wpc_out != nullptr) { *wpc_out = wpc; return 0; }
     const long total_waves = (long)C * wpc;
     const size_t lds = (size_t)WAVES * region;
     auto kern = dwconv_mfma_kernel<K, KS, MODE, NSEG>;
@@ -579,7 +614,7 @@ int launch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const u
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((total_waves + WAVES - 1) / WAVES)), dim3(64 * WAVES), lds, st, in0,
                        in1, wb, ws, o0, o1, N, C, H, W, G, band, bands, segs, items_per_channel, ipw, wpc,
-                       total_waves, tile_bytes, region);
+                       total_waves, tile_bytes, region, stats);
     return launch_status();
 }
 
@@ -592,20 +627,21 @@ inline long staged_cols(int W, int nseg) {
 
 template <int K, int KS, int MODE>
 int launch_k(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0,
-             uint16_t* o1, int N, int C, int H, int W, hipStream_t st) {
+             uint16_t* o1, int N, int C, int H, int W, hipStream_t st, float* stats, int* wpc_out) {
     const long c5 = staged_cols<K>(W, 5), c3 = staged_cols<K>(W, 3), c2 = staged_cols<K>(W, 2);
-    if (c5 <= c3 && c5 <= c2) return launch<K, KS, MODE, 5>(in0, in1, wb, ws, o0, o1, N, C, H, W, st);
-    if (c3 <= c2) return launch<K, KS, MODE, 3>(in0, in1, wb, ws, o0, o1, N, C, H, W, st);
-    return launch<K, KS, MODE, 2>(in0, in1, wb, ws, o0, o1, N, C, H, W, st);
+    if (c5 <= c3 && c5 <= c2) return launch<K, KS, MODE, 5>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out);
+    if (c3 <= c2) return launch<K, KS, MODE, 3>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out);
+    return launch<K, KS, MODE, 2>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out);
 }
 
 template <int MODE>
 int dispatch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0,
-             uint16_t* o1, int N, int C, int H, int W, int K, int KS, hipStream_t st) {
+             uint16_t* o1, int N, int C, int H, int W, int K, int KS, hipStream_t st, float* stats = nullptr,
+             int* wpc_out = nullptr) {
 #define PPEA_CASE(K_)                                                                             \
     case K_:                                                                                      \
-        return KS == 5 ? launch_k<K_, 5, MODE>(in0, in1, wb, ws, o0, o1, N, C, H, W, st)          \
-                       : launch_k<K_, 0, MODE>(in0, in1, wb, ws, o0, o1, N, C, H, W, st);
+        return KS == 5 ? launch_k<K_, 5, MODE>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out)   \
+                       : launch_k<K_, 0, MODE>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out);
     switch (K) {
         PPEA_CASE(31) PPEA_CASE(29) PPEA_CASE(27) PPEA_CASE(13)
         default: return PPEA_ERR_UNSUPPORTED;
@@ -645,6 +681,25 @@ int ppea_dwconv_lk_fwd_bf16p(const uint16_t* x, const void* packed_big, const vo
     if (KS != 0 && KS != 5) return PPEA_ERR_UNSUPPORTED;
     return dispatch<0>(x, nullptr, (const uint16_t*)packed_big, (const uint16_t*)packed_small, y_big, y_small, N, C,
                        H, W, K, KS, (hipStream_t)stream);
+}
+
+// Forward as above plus the statistics of the two BatchNorms that follow (rka.py:232-239): stats [2][C][P][2] fp32 =
+// per channel and wave of the channel (sum, sum of squares) of the stored y_big (first half) and y_small values,
+// P = ppea_dwconv_lk_stats_partials(N, C, H, W, K, KS); reduce each half with ppea_bn_finalize_sums_f32.
+int ppea_dwconv_lk_stats_partials(int N, int C, int H, int W, int K, int KS) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || (KS != 0 && KS != 5)) return 0;
+    int wpc = 0;
+    const int err = dispatch<0>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, C, H, W, K, KS, nullptr, nullptr, &wpc);
+    return err == 0 ? wpc : 0;
+}
+int ppea_dwconv_lk_fwd_stats_bf16p(const uint16_t* x, const void* packed_big, const void* packed_small, uint16_t* y_big,
+                                   uint16_t* y_small, float* stats, int N, int C, int H, int W, int K, int KS,
+                                   void* stream) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || stats == nullptr) return PPEA_ERR_UNSUPPORTED;
+    if (packed_small == nullptr || y_small == nullptr) KS = 0;
+    if (KS != 0 && KS != 5) return PPEA_ERR_UNSUPPORTED;
+    return dispatch<0>(x, nullptr, (const uint16_t*)packed_big, (const uint16_t*)packed_small, y_big, y_small, N, C,
+                       H, W, K, KS, (hipStream_t)stream, stats, nullptr);
 }
 
 int ppea_dwconv_lk_bwd_data_bf16p(const uint16_t* dy_big, const uint16_t* dy_small, const void* packed_big_flip,

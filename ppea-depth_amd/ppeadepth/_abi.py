@@ -117,6 +117,8 @@ SIGNATURES = {
     "ppea_nhwc_up2cat_fwd_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ppea_nhwc_up2cat_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ppea_nhwc_up2cat_bwd_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ppea_dwconv_lk_stats_partials": [_i] * 6,
+    "ppea_dwconv_lk_fwd_stats_bf16p": [_vp] * 6 + [_i] * 6 + [_vp],
     "ppea_pwconv_stats_partials": [_i] * 4,
     "ppea_pwconv_stats_bf16": [_vp] * 5 + [_i] * 4 + [_vp],
     "ppea_bn_finalize_sums_f32": [_vp, _i, _i, ctypes.c_long, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],

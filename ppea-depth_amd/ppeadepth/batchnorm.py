@@ -144,13 +144,14 @@ def _global_stats(bn, z, sums=None):
 PACK_PAIR = __import__("os").environ.get("PPEA_BN_PAIR", "1") == "1"
 
 
-def _global_stats_pair(bn1, z1, bn2, z2):
+def _global_stats_pair(bn1, z1, bn2, z2, sums=None):
     """Two BNs over tensors that exist at the same time (the k x k and 5 x 5 branches of a re-parameterised large-kernel
     conv, rka.py:232-239): their SyncBN statistics travel in ONE packed all-gather instead of two."""
     from . import ops
     if not (PACK_PAIR and bn1.sync and bn2.sync and _collectives_on()) \
             or getattr(bn1, "group", None) is not getattr(bn2, "group", None):
-        return _global_stats(bn1, z1), _global_stats(bn2, z2)
+        s1, s2 = sums if sums is not None else (None, None)
+        return _global_stats(bn1, z1, s1), _global_stats(bn2, z2, s2)
     group = getattr(bn1, "group", None)
     world = dist.get_world_size(group)
     p1, p2 = ops.bn_local_stats_packed(z1), ops.bn_local_stats_packed(z2)
@@ -219,10 +220,10 @@ def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None,
     count, group = None, None
     pre = None
     if z2 is not None and bn1.training and bn2.training:
-        pre = list(_global_stats_pair(bn1, z1, bn2, z2))
+        pre = list(_global_stats_pair(bn1, z1, bn2, z2, sums if isinstance(sums, tuple) else None))
     for z, bn in bns:
         if bn.training:
-            mean, invstd, count, group = pre.pop(0) if pre is not None else _global_stats(bn, z, sums if z is z1 else None)
+            mean, invstd, count, group = pre.pop(0) if pre is not None else _global_stats(bn, z, sums if (z is z1 and not isinstance(sums, tuple)) else None)
             if _ACTIVE_DEFERRED is None:
                 bn.num_batches_tracked += 1
             else:

@@ -162,6 +162,7 @@ class PointwiseConv(nn.Conv2d):
 
 
 PW_MFMA = True
+DW_SUMS = os.environ.get("PPEA_DW_SUMS", "1") == "1"   # ... and from the large-kernel depthwise conv's epilogue
 BN_SUMS = os.environ.get("PPEA_BN_SUMS", "1") == "1"   # BatchNorm statistics from the 1x1 conv's epilogue (stages 0 / 1)
 ADAPTER_MFMA = True    # adapters (forward + every gradient) on the NCHW MFMA kernels under bf16
 
@@ -321,6 +322,12 @@ class ReparamLargeKernelConv(nn.Module):
         """act(BN(DW_k(x)) + BN(DW_5(x))): one conv launch + fused BN/activation."""
         big, small = self.lkb_origin.conv, self.small_conv.conv
         if isinstance(big, LargeKernelDW) and small.kernel_size[0] in (3, 5) and small.stride[0] == 1:
+            if (FUSE_BN and BN_SUMS and DW_SUMS and self.training and x.is_cuda and x.dtype == torch.bfloat16
+                    and x.shape[0] * x.shape[2] * x.shape[3] > 16384):
+                # stages 0 / 1: the conv's epilogue also leaves the per-channel sums the two BatchNorms need
+                y_big, y_small, sums = ops.dwconv_lk(x, big.weight, small.weight, want_sums=True)
+                return fused_bn_act(y_big, self.lkb_origin.bn, y_small, self.small_conv.bn, act=act,
+                                    sums=None if sums is None else (sums[0], sums[1]))
             y_big, y_small = ops.dwconv_lk(x, big.weight, small.weight)
             if FUSE_BN and self.training and x.is_cuda:
                 return fused_bn_act(y_big, self.lkb_origin.bn, y_small, self.small_conv.bn, act=act)

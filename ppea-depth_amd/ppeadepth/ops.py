@@ -79,7 +79,7 @@ def _mfma_ok(x, K, KS):
 # ---------------------------------------------------------------------------------------------
 class _DwConvLK(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_big, w_small):
+    def forward(ctx, x, w_big, w_small, want_sums=False):
         x = x.contiguous()
         N, C, H, W = x.shape
         K = w_big.shape[-1]
@@ -90,11 +90,23 @@ class _DwConvLK(torch.autograd.Function):
         y_small = torch.empty_like(x) if KS else None
         ctx.packed = None
         done = False
+        sums = None
         if _mfma_ok(x, K, KS):
             pb = _packed_filter(w_big, False)
             ps = _packed_filter(w_small, False) if KS else None
-            err = _timed("fwd31", K, lambda: _abi.lib.ppea_dwconv_lk_fwd_bf16p(
-                ptr(x), ptr(pb), ptr(ps), ptr(y_big), ptr(y_small), N, C, H, W, K, KS, stream_ptr()))
+            P = _abi.lib.ppea_dwconv_lk_stats_partials(N, C, H, W, K, KS) if (want_sums and KS) else 0
+            err = -1
+            if P > 0:
+                # per-channel partial sums of both outputs from the conv's epilogue: the BatchNorm pair after it needs
+                # no statistics pass (batchnorm.fused_bn_act(..., sums=(sums[0], sums[1])))
+                sums = torch.empty(2, C, P, 2, device=x.device, dtype=_F32)
+                err = _timed("fwd31", K, lambda: _abi.lib.ppea_dwconv_lk_fwd_stats_bf16p(
+                    ptr(x), ptr(pb), ptr(ps), ptr(y_big), ptr(y_small), ptr(sums), N, C, H, W, K, KS, stream_ptr()))
+                if err != 0:
+                    sums = None
+            if sums is None:
+                err = _timed("fwd31", K, lambda: _abi.lib.ppea_dwconv_lk_fwd_bf16p(
+                    ptr(x), ptr(pb), ptr(ps), ptr(y_big), ptr(y_small), N, C, H, W, K, KS, stream_ptr()))
             if err == 0:
                 done = True
                 ctx.packed = (w_big, w_small)
@@ -106,12 +118,16 @@ class _DwConvLK(torch.autograd.Function):
         ctx.save_for_backward(x, wb, ws)
         ctx.has_small = KS > 0
         ctx.w_dtypes = (w_big.dtype, None if w_small is None else w_small.dtype)
+        if want_sums:
+            if sums is not None:
+                ctx.mark_non_differentiable(sums)
+            return y_big, (y_small if KS else None), sums
         if KS:
             return y_big, y_small
         return y_big, None
 
     @staticmethod
-    def backward(ctx, dy_big, dy_small):
+    def backward(ctx, dy_big, dy_small, _dsums=None):
         x, wb, ws = ctx.saved_tensors
         N, C, H, W = x.shape
         K = wb.shape[-1]
@@ -150,11 +166,15 @@ class _DwConvLK(torch.autograd.Function):
             call("ppea_dwconv_lk_bwd_filter_f32", ptr(x.float().contiguous()),
                  ptr(dy_small.float().contiguous()), ptr(dws), N, C, H, W, KS, stream_ptr())
             dws = dws.to(ctx.w_dtypes[1])
-        return dx, dwb, dws
+        return dx, dwb, dws, None
 
 
-def dwconv_lk(x, w_big, w_small=None):
-    """(DW_k(x), DW_ks(x)) with stride 1 / pad k//2 / no bias; second is None without w_small."""
+def dwconv_lk(x, w_big, w_small=None, want_sums=False):
+    """(DW_k(x), DW_ks(x)) with stride 1 / pad k//2 / no bias; second is None without w_small.
+    want_sums: -> (y_big, y_small, sums [2, C, P, 2] or None): per-channel partial (sum, sum of squares) of both outputs
+    from the conv's epilogue, for the two BatchNorms that follow."""
+    if want_sums:
+        return _DwConvLK.apply(x, w_big, w_small, True)
     return _DwConvLK.apply(x, w_big, w_small)
 
 

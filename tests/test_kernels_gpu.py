@@ -995,3 +995,23 @@ def test_pwconv_epilogue_sums_give_the_batchnorm_statistics(device, shape):
     assert rel_err(mean.cpu(), want_mean.cpu()) < 1e-6 and rel_err(var.cpu(), want_var.cpu()) < 1e-5
     assert rel_err(invstd.cpu(), (want_var + 1e-5).rsqrt().cpu()) < 1e-5
     assert rel_err(rm.cpu(), rm_ref.cpu()) < 1e-5 and rel_err(rv.cpu(), rv_ref.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(12, 128, 48, 160, 31), (12, 256, 24, 80, 29), (3, 64, 20, 36, 13)])
+def test_dwconv_epilogue_sums_give_both_batchnorm_statistics(device, shape):
+    """The large-kernel depthwise conv's epilogue returns per-channel partial sums of BOTH outputs (k x k and 5 x 5 branch,
+    rka.py:232-239): same output bytes as the plain launch, and statistics of the stored bf16 tensors to 1e-6 / 1e-5."""
+    from ppeadepth import ops
+    N, C, H, W, K = shape
+    g = _g(N + C + K)
+    x = torch.randn(N, C, H, W, generator=g).bfloat16().to(device)
+    wb = (torch.randn(C, 1, K, K, generator=g) / K).to(device)
+    ws = (torch.randn(C, 1, 5, 5, generator=g) / 5).to(device)
+    yb0, ys0 = ops.dwconv_lk(x, wb, ws)
+    yb, ys, sums = ops.dwconv_lk(x, wb, ws, want_sums=True)
+    assert sums is not None and torch.equal(yb, yb0) and torch.equal(ys, ys0)
+    for y, s in ((yb, sums[0]), (ys, sums[1])):
+        mean, var, invstd = ops.bn_batch_stats_from_sums(s.contiguous(), N * H * W, 1e-5, 0.1, None, None)
+        yf = y.double()
+        assert rel_err(mean.cpu(), yf.mean((0, 2, 3)).cpu()) < 1e-6
+        assert rel_err(var.cpu(), yf.var((0, 2, 3), unbiased=False).cpu()) < 1e-5
