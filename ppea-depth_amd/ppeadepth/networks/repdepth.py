@@ -28,6 +28,10 @@ BATCHED_POSES = True      # third (no_grad) pose pass replayed instead of recomp
 POSE_ONE_BATCH = True      # both pairs as one 2B batch with per-pair BN statistics (needs the fused NHWC BN path)
 import os as _os
 POSE_ON_TEACHER_STREAM = _os.environ.get("PPEA_POSE_ON_SIDE", "0") == "1"
+# the pose network as a third parallel branch: forked at the start of the step, joined where the student needs the matching
+# frame's pose (the cost volume) -- its backward then depends only on the loss and can run under the student's backward
+# instead of after it
+POSE_OWN_STREAM = _os.environ.get("PPEA_POSE_STREAM", "0") == "1"
 
 
 def _g(opt, name, default):
@@ -236,6 +240,24 @@ class RepDepth(nn.Module):
             side.wait_stream(torch.cuda.current_stream())
         try:
             pose_pred = None
+            pose_join = None
+            if side is not None and POSE_OWN_STREAM and not self.freeze_pose and not POSE_ON_TEACHER_STREAM:
+                main = torch.cuda.current_stream()
+                ps = getattr(self, "_pose_side", None)
+                if ps is None or ps.device != img_aug.device:
+                    ps = self._pose_side = torch.cuda.Stream(img_aug.device)
+                    from . import replknet_adapter
+                    replknet_adapter.NO_FORK_ON.add(ps.cuda_stream)
+                ps.wait_stream(main)
+                with torch.cuda.stream(ps):
+                    pose_pred = self.predict_poses(inputs)
+                    pose_ready = torch.cuda.Event()
+                    pose_ready.record(ps)
+
+                def pose_join(pose_pred=pose_pred, pose_ready=pose_ready, main=main):
+                    main.wait_event(pose_ready)
+                    for v in list(pose_pred.values()) + [inputs[("relative_pose", i)] for i in self.matching_ids[1:]]:
+                        v.record_stream(main)
             if side is not None:
                 with torch.cuda.stream(side):
                     if POSE_ON_TEACHER_STREAM and not self.freeze_pose:
@@ -246,7 +268,7 @@ class RepDepth(nn.Module):
                         pose_ready = torch.cuda.Event()
                         pose_ready.record(side)
                     mono_outputs.update(self.mono_depth(self.mono_encoder(img_aug)))
-                if pose_pred is not None:
+                if pose_pred is not None and pose_join is None:
                     main = torch.cuda.current_stream()
                     main.wait_event(pose_ready)
                     for v in list(pose_pred.values()) + [inputs[("relative_pose", i)] for i in self.matching_ids[1:]]:
@@ -261,7 +283,6 @@ class RepDepth(nn.Module):
             outputs.update(pose_pred)
             mono_outputs.update(pose_pred)
 
-            relative_poses = torch.stack([inputs[("relative_pose", i)] for i in self.matching_ids[1:]], 1)
             lookup_frames = torch.stack([inputs[("color_aug", i, 0)] for i in self.matching_ids[1:]], 1)
             device = lookup_frames.device
             B = lookup_frames.shape[0]
@@ -274,8 +295,15 @@ class RepDepth(nn.Module):
             cur = inputs[("color", 0, 0)]
             lookup_frames = torch.where(static[:, None, None, None, None], cur[:, None].expand_as(lookup_frames),
                                         lookup_frames)
-            relative_poses = relative_poses * (~nopose).to(relative_poses.dtype)[:, None, None, None]
             outputs["augmentation_mask"] = (static | nopose).float().reshape(B, 1, 1, 1)
+
+            def relative_poses():
+                # evaluated by the matching encoder right before the cost volume: with the pose network on its own stream
+                # this is where the step waits for it (stem + stage 0 of both frames do not need the pose)
+                if pose_join is not None:
+                    pose_join()
+                rp = torch.stack([inputs[("relative_pose", i)] for i in self.matching_ids[1:]], 1)
+                return rp * (~nopose).to(rp.dtype)[:, None, None, None]
 
             if side is not None:
                 pass

@@ -95,6 +95,8 @@ class RepLKMatchingAdapter(nn.Module):
             if Fr != 1:
                 raise NotImplementedError("hot path uses one lookup frame (num_matching_frames=1)")
             lookup_feats, _ = self.feature_extraction(lookup_images.reshape(B * Fr, ch, H, W))
+            if callable(poses):
+                poses = poses()
             raw = ops.cost_volume(self.features[-1].float(), lookup_feats.float(), poses[:, 0], K, invK,
                                   self.depth_bins)
             cost_volume, confidence_mask, argmin, lowest_cost = ops.cost_volume_reduce(raw, self.depth_bins)
