@@ -33,7 +33,7 @@ def get_bn(channels):
     return BatchNorm2d(channels, sync=use_sync_bn)
 
 
-ADAPTER_STREAMS = True   # adapter branch of every block on a side stream (parallel branch of the step graph)
+ADAPTER_STREAMS = os.environ.get("PPEA_ADAPTER_STREAMS", "1") == "1"   # adapters of the student on a forked side stream
 _SIDE = {}
 NO_FORK_ON = set()       # cuda_stream handles on which adapters run inline (already a forked branch)
 
