@@ -162,7 +162,9 @@ class PointwiseConv(nn.Conv2d):
 
 
 PW_MFMA = True
-DW_SUMS = os.environ.get("PPEA_DW_SUMS", "1") == "1"   # ... and from the large-kernel depthwise conv's epilogue
+# ... and from the large-kernel depthwise conv's epilogue: measured neutral for the step, but the 16 conversions + FMAs per
+# tile sit in the hand-pipelined kernel's instruction stream (31x31 forward 74 -> 82 us), so it is opt-in (PPEA_DW_SUMS=1)
+DW_SUMS = os.environ.get("PPEA_DW_SUMS", "0") == "1"
 BN_SUMS = os.environ.get("PPEA_BN_SUMS", "1") == "1"   # BatchNorm statistics from the 1x1 conv's epilogue (stages 0 / 1)
 ADAPTER_MFMA = True    # adapters (forward + every gradient) on the NCHW MFMA kernels under bf16
 

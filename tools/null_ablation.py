@@ -10,7 +10,8 @@ from ppeadepth import _abi
 tags = [t for t in os.environ.get("PPEA_NULL", "").split(",") if t]
 n = 0
 for name in _abi.SIGNATURES:
-    if name.endswith("_bytes") or name in ("ppea_abi_version", "ppea_nhwc_bn_slabs", "ppea_nhwc_bias_elu_slabs"):
+    if name.endswith("_bytes") or name.endswith("_partials") or name in ("ppea_abi_version", "ppea_nhwc_bn_slabs",
+                                                                          "ppea_nhwc_bias_elu_slabs"):
         continue
     if any(name.startswith("ppea_" + t) for t in tags):
         setattr(_abi.lib, name, lambda *a: 0)
