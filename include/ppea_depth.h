@@ -199,6 +199,25 @@ int ppea_bn_bwd_channel_f32(const void* dy, const void* z1, const void* z2, cons
 int ppea_bn_bwd_channel_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats, const float* mask,
                              float inv_count, const void* acc, void* dz1, void* dz2, float* sums, int act, int N, int C,
                              int HW, void* stream);
+/* End of one block and the first BatchNorm of the next in one launch per direction (replknet_adapter.py:283-289,
+ * 315-326 followed by the next block's prelkb_bn / preffn_bn, :281, :312): y = mask * BN_A(z) + r1 + r2_scale * r2,
+ * y2 = BN_B(y) with BN_B's statistics taken of the stored y.  prm = {gammaA, betaA, gammaB, betaB}; out = {running_meanA,
+ * running_varA, running_meanB, running_varB (NULL: no update), meanA, invstdA, meanB, invstdB (written)}.  Backward:
+ * stats = {meanA, invstdA, gammaA, betaA, meanB, invstdB, gammaB, betaB}; dskip = gradient of y from its other consumer
+ * (NULL: none); writes dz, dy (total gradient of y) and sums [4][C] = dbetaA | dgammaA | dbetaB | dgammaB.
+ * Results are bit-identical to ppea_bn_fwd_channel_* / ppea_bn_bwd_channel_* applied twice. */
+int ppea_bn_fwd_channel_next_f32(const void* z, const float* const* prm, float* const* out, float eps, float momentum,
+                                 const float* mask, const void* r1, const void* r2, float r2_scale, void* y, void* y2,
+                                 int N, int C, int HW, void* stream);
+int ppea_bn_fwd_channel_next_bf16(const void* z, const float* const* prm, float* const* out, float eps, float momentum,
+                                  const float* mask, const void* r1, const void* r2, float r2_scale, void* y, void* y2,
+                                  int N, int C, int HW, void* stream);
+int ppea_bn_bwd_channel_next_f32(const void* dy2, const void* dskip, const void* z, const void* y, const float* const* stats,
+                                 const float* mask, float inv_count, void* dz, void* dy, float* sums, int N, int C, int HW,
+                                 void* stream);
+int ppea_bn_bwd_channel_next_bf16(const void* dy2, const void* dskip, const void* z, const void* y, const float* const* stats,
+                                  const float* mask, float inv_count, void* dz, void* dy, float* sums, int N, int C, int HW,
+                                  void* stream);
 int ppea_bn_apply_f32(const void* z1, const void* z2, const float* const* stats, const float* mask,
                       const void* r1, const void* r2, float r2_scale, void* y, int act,
                       int N, int C, int HW, void* stream);

@@ -702,6 +702,184 @@ __global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, 
     }
 }
 
+// ---- end of one block + start of the next in ONE launch per direction ---------------------------------------------------
+// A block ends with  x' = x + mask * BN_A(z) + s * adapter  (rka.py:283-289, 315-326) and the next block starts with
+// out' = BN_B(x') (its prelkb_bn / preffn_bn).  Both are per-channel passes over the same tensor, and at stages 2 / 3 the
+// step's wall time is the number of dependent launches: the workgroup that owns the channel keeps x' in registers, takes
+// BN_B's statistics of the STORED (rounded) values and writes out' as well.  Backward likewise:
+//   dx' = BN_B-backward(d out') + (gradient of x' from its other use, the next block's residual);  dz = BN_A-backward(mask dx').
+// Arithmetic, rounding points and running-statistics updates are those of the two separate launches (bit-identical results).
+struct NextPrm { const float *gammaA, *betaA, *gammaB, *betaB; float *rmA, *rvA, *rmB, *rvB, *meanA, *invstdA, *meanB, *invstdB; };
+
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_fwd_channel_next(const T* __restrict__ z, NextPrm p, float eps, float momentum,
+                                                           const float* __restrict__ mask, const T* __restrict__ r1,
+                                                           const T* __restrict__ r2, float r2_scale, T* __restrict__ y,
+                                                           T* __restrict__ y2, int N, int C, int HW) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const int hv = HW / V, total = N * hv;
+    const float cnt = (float)N * (float)HW;
+    float x[CH_VECS][V];
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j < total) {
+            const int n = j / hv, i = j - n * hv;
+            ld8<T>(z + ((long)n * C + c) * HW + i * V, x[u]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) x[u][k] = 0.f;
+        }
+    }
+    // two-pass statistics of the register-resident values (valid elements only); returns (mean, sum of squared deviations)
+    auto stats = [&](float& mu, float& q) {
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < CH_VECS; ++u)
+#pragma unroll
+            for (int k = 0; k < V; ++k) s += x[u][k];
+        mu = block_sum(s, red) / cnt;
+        float qq = 0.f;
+#pragma unroll
+        for (int u = 0; u < CH_VECS; ++u)
+            if (threadIdx.x + u * TPB < total) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) qq += (x[u][k] - mu) * (x[u][k] - mu);
+            }
+        q = block_sum(qq, red);
+    };
+    float muA, qA;
+    stats(muA, qA);
+    const float isA = rsqrtf(qA / cnt + eps);
+    if (threadIdx.x == 0) {
+        p.meanA[c] = muA; p.invstdA[c] = isA;
+        if (p.rmA != nullptr) {
+            p.rmA[c] = (1.f - momentum) * p.rmA[c] + momentum * muA;
+            p.rvA[c] = (1.f - momentum) * p.rvA[c] + momentum * (qA / fmaxf(cnt - 1.f, 1.f));
+        }
+    }
+    const float aA = p.gammaA[c] * isA, oA = p.betaA[c] - muA * aA;
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j < total) {
+            const int n = j / hv, i = j - n * hv;
+            const long off = ((long)n * C + c) * HW + i * V;
+            const float m = (mask != nullptr) ? mask[n] : 1.f;
+            float e1[V], e2[V];
+            if (r1 != nullptr) ld8<T>(r1 + off, e1);
+            if (r2 != nullptr) ld8<T>(r2 + off, e2);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float v = (aA * x[u][k] + oA) * m;
+                if (r1 != nullptr) v += e1[k];
+                if (r2 != nullptr) v += r2_scale * e2[k];
+                x[u][k] = round_as<T>(v);                  // what the next block reads back
+            }
+            st8<T>(y + off, x[u]);
+        }
+    }
+    float muB, qB;
+    stats(muB, qB);
+    const float isB = rsqrtf(qB / cnt + eps);
+    if (threadIdx.x == 0) {
+        p.meanB[c] = muB; p.invstdB[c] = isB;
+        if (p.rmB != nullptr) {
+            p.rmB[c] = (1.f - momentum) * p.rmB[c] + momentum * muB;
+            p.rvB[c] = (1.f - momentum) * p.rvB[c] + momentum * (qB / fmaxf(cnt - 1.f, 1.f));
+        }
+    }
+    const float aB = p.gammaB[c] * isB, oB = p.betaB[c] - muB * aB;
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j < total) {
+            const int n = j / hv, i = j - n * hv;
+            float o[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) o[k] = aB * x[u][k] + oB;
+            st8<T>(y2 + ((long)n * C + c) * HW + i * V, o);
+        }
+    }
+}
+
+// sums [4][C] = d betaA | d gammaA | d betaB | d gammaB
+template <typename T>
+__global__ __launch_bounds__(TPB) void bn_bwd_channel_next(const T* __restrict__ dy2, const T* __restrict__ dskip,
+                                                           const T* __restrict__ z, const T* __restrict__ y, Branch A,
+                                                           Branch B, const float* __restrict__ mask, float inv_count,
+                                                           T* __restrict__ dz, T* __restrict__ dy, float* __restrict__ sums,
+                                                           int N, int C, int HW) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const int hv = HW / V, total = N * hv;
+    const float isA = A.invstd[c], muA = A.mean[c], aA = A.gamma[c] * isA;
+    const float isB = B.invstd[c], muB = B.mean[c], aB = B.gamma[c] * isB;
+    float g[CH_VECS][V], xd[CH_VECS][V];                    // gradient in flight, input - mean of the current BN
+    float sg = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j < total) {
+            const int n = j / hv, i = j - n * hv;
+            const long off = ((long)n * C + c) * HW + i * V;
+            ld8<T>(dy2 + off, g[u]);
+            ld8<T>(y + off, xd[u]);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                xd[u][k] = xd[u][k] - muB;
+                sg += g[u][k];
+                s1 += g[u][k] * xd[u][k] * isB;              // operation order of bn_bwd_channel (bit-identical sums)
+            }
+        }
+    }
+    sg = block_sum(sg, red); s1 = block_sum(s1, red);
+    if (threadIdx.x == 0) { sums[2 * C + c] = sg; sums[3 * C + c] = s1; }
+    float mg = sg * inv_count, m1 = s1 * inv_count;
+    sg = 0.f; s1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j < total) {
+            const int n = j / hv, i = j - n * hv;
+            const long off = ((long)n * C + c) * HW + i * V;
+            const float m = (mask != nullptr) ? mask[n] : 1.f;
+            float ea[V], zz[V];
+            if (dskip != nullptr) ld8<T>(dskip + off, ea);
+            ld8<T>(z + off, zz);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float e = round_as<T>(aB * (g[u][k] - mg - xd[u][k] * isB * m1));   // BN_B backward, as its own launch stores it
+                if (dskip != nullptr) e = round_as<T>(e + ea[k]);               // + the residual use's gradient
+                g[u][k] = e;
+            }
+            st8<T>(dy + off, g[u]);                          // d x': to the block's input (residual) and, scaled, to the adapter
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                g[u][k] *= m;
+                xd[u][k] = zz[k] - muA;
+                sg += g[u][k];
+                s1 += g[u][k] * xd[u][k] * isA;
+            }
+        }
+    }
+    sg = block_sum(sg, red); s1 = block_sum(s1, red);
+    if (threadIdx.x == 0) { sums[c] = sg; sums[C + c] = s1; }
+    mg = sg * inv_count; m1 = s1 * inv_count;
+#pragma unroll
+    for (int u = 0; u < CH_VECS; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j < total) {
+            const int n = j / hv, i = j - n * hv;
+            float o[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) o[k] = aA * (g[u][k] - mg - xd[u][k] * isA * m1);
+            st8<T>(dz + ((long)n * C + c) * HW + i * V, o);
+        }
+    }
+}
+
 constexpr long CHANNEL_ELEMS = 16384;       // N * HW up to here: the wave-per-channel kernels
 
 // ---- flat element-wise passes (HW % 8 == 0): 8 elements per thread, channel looked up per thread -------
@@ -926,7 +1104,55 @@ int bwd_channel_impl(const void* dy, const void* z1, const void* z2, const float
     return launch_status();
 }
 
+template <typename T>
+int fwd_channel_next_impl(const void* z, const float* const* prm, float* const* outp, float eps, float momentum,
+                          const float* mask, const void* r1, const void* r2, float r2_scale, void* y, void* y2, int N, int C,
+                          int HW, void* stream) {
+    if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS) return PPEA_ERR_UNSUPPORTED;
+    NextPrm p{prm[0], prm[1], prm[2], prm[3], outp[0], outp[1], outp[2], outp[3], outp[4], outp[5], outp[6], outp[7]};
+    hipLaunchKernelGGL(bn_fwd_channel_next<T>, dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)z, p, eps,
+                       momentum, mask, (const T*)r1, (const T*)r2, r2_scale, (T*)y, (T*)y2, N, C, HW);
+    return launch_status();
+}
+template <typename T>
+int bwd_channel_next_impl(const void* dy2, const void* dskip, const void* z, const void* y, const float* const* st,
+                          const float* mask, float inv_count, void* dz, void* dy, float* sums, int N, int C, int HW,
+                          void* stream) {
+    if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS) return PPEA_ERR_UNSUPPORTED;
+    Branch A{st[0], st[1], st[2], st[3]}, B{st[4], st[5], st[6], st[7]};
+    hipLaunchKernelGGL(bn_bwd_channel_next<T>, dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy2,
+                       (const T*)dskip, (const T*)z, (const T*)y, A, B, mask, inv_count, (T*)dz, (T*)dy, sums, N, C, HW);
+    return launch_status();
+}
+
 extern "C" {
+
+// End of a block + the next block's first BatchNorm in one launch (see bn_fwd_channel_next): y = mask * BN_A(z) + r1 +
+// r2_scale * r2, y2 = BN_B(y).  prm = {gammaA, betaA, gammaB, betaB}; out = {running_meanA, running_varA, running_meanB,
+// running_varB (NULL: no update), meanA, invstdA, meanB, invstdB (written)}.  Backward: dy2 = gradient of y2, dskip =
+// gradient of y from its other use (or NULL), stats = {meanA, invstdA, gammaA, betaA, meanB, invstdB, gammaB, betaB};
+// writes dz, dy (the total gradient of y: r1's gradient, and r2's after scaling) and sums [4][C] = d betaA | d gammaA |
+// d betaB | d gammaB.  Same limits as ppea_bn_fwd_channel_*.
+int ppea_bn_fwd_channel_next_f32(const void* z, const float* const* prm, float* const* out, float eps, float momentum,
+                                 const float* mask, const void* r1, const void* r2, float r2_scale, void* y, void* y2,
+                                 int N, int C, int HW, void* stream) {
+    return fwd_channel_next_impl<float>(z, prm, out, eps, momentum, mask, r1, r2, r2_scale, y, y2, N, C, HW, stream);
+}
+int ppea_bn_fwd_channel_next_bf16(const void* z, const float* const* prm, float* const* out, float eps, float momentum,
+                                  const float* mask, const void* r1, const void* r2, float r2_scale, void* y, void* y2,
+                                  int N, int C, int HW, void* stream) {
+    return fwd_channel_next_impl<uint16_t>(z, prm, out, eps, momentum, mask, r1, r2, r2_scale, y, y2, N, C, HW, stream);
+}
+int ppea_bn_bwd_channel_next_f32(const void* dy2, const void* dskip, const void* z, const void* y, const float* const* stats,
+                                 const float* mask, float inv_count, void* dz, void* dy, float* sums, int N, int C, int HW,
+                                 void* stream) {
+    return bwd_channel_next_impl<float>(dy2, dskip, z, y, stats, mask, inv_count, dz, dy, sums, N, C, HW, stream);
+}
+int ppea_bn_bwd_channel_next_bf16(const void* dy2, const void* dskip, const void* z, const void* y, const float* const* stats,
+                                  const float* mask, float inv_count, void* dz, void* dy, float* sums, int N, int C, int HW,
+                                  void* stream) {
+    return bwd_channel_next_impl<uint16_t>(dy2, dskip, z, y, stats, mask, inv_count, dz, dy, sums, N, C, HW, stream);
+}
 
 // One launch per BN for small channels (N * HW <= 16384, HW % 8 == 0, C >= 64; else PPEA_ERR_UNSUPPORTED):
 // prm = {gamma1, beta1, gamma2, beta2}; out = {running_mean1, running_var1, running_mean2, running_var2 (NULL: no

@@ -102,6 +102,10 @@ SIGNATURES = {
     "ppea_bn_fwd_channel_bf16": [_vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp],
     "ppea_bn_bwd_channel_f32": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_bn_bwd_channel_bf16": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_bn_fwd_channel_next_f32": [_vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
+    "ppea_bn_fwd_channel_next_bf16": [_vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
+    "ppea_bn_bwd_channel_next_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ppea_bn_bwd_channel_next_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ppea_conv_image_packed_bytes": [_i, _i],
     "ppea_conv_image_pack_weights": [_vp, _i, _vp, _i, _i, _i, _vp],
     "ppea_conv_image_bf16": [_vp, _vp, _vp] + [_i] * 10 + [_vp],

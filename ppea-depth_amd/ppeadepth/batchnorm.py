@@ -241,6 +241,33 @@ def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None,
     return (y, z1) if skip else y
 
 
+BN_CHAIN = __import__("os").environ.get("PPEA_BN_CHAIN", "1") == "1"
+
+
+def fused_bn_act_next(z, bnA, bnB, mask=None, r1=None, r2=None, r2_scale=1.0):
+    """A block's last BatchNorm (+ DropPath + residual + adapter) and the NEXT block's first BatchNorm in one launch
+    per direction: -> (y, y2) = (mask * BN_A(z) + r1 + r2_scale * r2, BN_B(y)), or None when the shape / mode is not
+    served by the one-launch channel kernels (the caller then runs the two BatchNorms separately).  Same numbers, running
+    statistics and bookkeeping as fused_bn_act(z, bnA, ...) followed by fused_bn_act(y, bnB, skip=True)."""
+    from . import ops
+    if not (BN_CHAIN and ops.bn_channel_ok(z) and bnA.training and bnB.training
+            and not ((bnA.sync or bnB.sync) and _collectives_on())
+            and bnA.eps == bnB.eps and bnA.momentum == bnB.momentum
+            and bnA.running_mean.dtype == torch.float32 and bnB.running_mean.dtype == torch.float32
+            and bnA.num_features == bnB.num_features):
+        return None
+    y, y2, st = ops.bn_act_channel_next(z, bnA, bnB, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale)
+    cnt = float(z.numel() // z.shape[1])
+    for k, bn in enumerate((bnA, bnB)):
+        if _ACTIVE_DEFERRED is None:
+            bn.num_batches_tracked += 1
+        else:
+            _ACTIVE_DEFERRED.count(bn)
+            if bn.replay_update and torch.is_grad_enabled():
+                _ACTIVE_DEFERRED.add(bn, st[2 * k], st[2 * k + 1], cnt)
+    return y, y2
+
+
 class BatchNorm2d(nn.Module):
     """Drop-in for nn.BatchNorm2d / nn.SyncBatchNorm (same parameters, buffers, state_dict keys)."""
 

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops, rng
-from ..batchnorm import BatchNorm2d, fused_bn_act
+from ..batchnorm import BatchNorm2d, fused_bn_act, fused_bn_act_next
 
 FUSE_BN = True      # training-mode BN + activation + residual glue on the fused HIP kernels
 ADAPTER_CHANNELS_LAST = True
@@ -47,10 +47,15 @@ def _forked_adapter(adapter, inp):
     if side is None:
         side = _SIDE[key] = torch.cuda.Stream(inp.device)
     side.wait_stream(main)
+    # `inp` was allocated on `main` but the adapter SAVES it for backward, where side-stream kernels read it (the weight
+    # gradient of D_fc1) right before autograd drops the last reference: without this mark the allocator hands the
+    # block back to `main` while those kernels may still be running (found in round 2: D_fc1.weight.grad differed
+    # in the last bits between the forked and the in-line adapter).
+    inp.record_stream(side)
     with torch.cuda.stream(side):
         out = adapter(inp)
-    # No record_stream needed: `inp` outlives the block, and `out` returns to the side stream's pool only
-    # after the consumer on `main` has been enqueued -- the next fork waits for `main` before reusing it.
+    # `out` needs no mark: it returns to the side stream's pool only after the consumer on `main` has been enqueued,
+    # and the next fork waits for `main` before reusing it.
     return out, lambda: main.wait_stream(side)
 
 
@@ -379,9 +384,16 @@ class ConvFFN(nn.Module):
             self.mlp_adapter = Adapter(in_channels, adpt_test, 0.5 if adpt_test == 2 else 0.25)
         self.gamma, self.test_id = gamma, adpt_test
 
-    def forward(self, x):
+    pre_bn = property(lambda self: self.preffn_bn)
+
+    def forward(self, x, pre_out=None, next_bn=None):
+        """pre_out: preffn_bn(x), already computed by the previous block's last launch; next_bn: the following block's
+        first BatchNorm -- computed here, in this block's last launch: -> (y, next_bn(y)) (see fused_bn_act_next)."""
         if FUSE_BN and self.training and x.is_cuda:
-            out, x = fused_bn_act(x, self.preffn_bn, skip=True)    # x: the same tensor, routed for the residual use
+            if pre_out is not None:
+                out = pre_out
+            else:
+                out, x = fused_bn_act(x, self.preffn_bn, skip=True)    # x: the same tensor, routed for the residual use
             adpt, join = None, None
             if self.test_id >= 0:
                 if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
@@ -393,8 +405,14 @@ class ConvFFN(nn.Module):
             z, s2 = _conv_sums(self.pw2.conv, h)
             if join is not None:
                 join()
-            return fused_bn_act(z, self.pw2.bn, mask=_drop_mask(self.drop_path, x), r1=x, r2=adpt,
-                                r2_scale=self.gamma, sums=s2)
+            mask = _drop_mask(self.drop_path, x)
+            if next_bn is not None:
+                pair = fused_bn_act_next(z, self.pw2.bn, next_bn, mask=mask, r1=x, r2=adpt, r2_scale=self.gamma)
+                if pair is not None:
+                    return pair
+            y = fused_bn_act(z, self.pw2.bn, mask=mask, r1=x, r2=adpt, r2_scale=self.gamma, sums=s2)
+            return y if next_bn is None else (y, None)
+        assert pre_out is None and next_bn is None
         out = self.preffn_bn(x)
         adpt = self.mlp_adapter(out) if self.test_id >= 0 else None
         out = self.pw2(self.nonlinear(self.pw1(out)))
@@ -419,9 +437,15 @@ class RepLKBlock(nn.Module):
             self.adapter = B_Adapter(in_channels, adpt_test, ratio)
         self.gamma, self.test_id = gamma, adpt_test
 
-    def forward(self, x):
+    pre_bn = property(lambda self: self.prelkb_bn)
+
+    def forward(self, x, pre_out=None, next_bn=None):
+        """pre_out / next_bn: see ConvFFN.forward."""
         if FUSE_BN and self.training and x.is_cuda and hasattr(self.large_kernel, "small_conv"):
-            out, x = fused_bn_act(x, self.prelkb_bn, skip=True)    # x: the same tensor, routed for the residual use
+            if pre_out is not None:
+                out = pre_out
+            else:
+                out, x = fused_bn_act(x, self.prelkb_bn, skip=True)    # x: the same tensor, routed for the residual use
             adpt, join = None, None
             if self.test_id >= 0:
                 if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
@@ -432,8 +456,14 @@ class RepLKBlock(nn.Module):
             z, s2 = _conv_sums(self.pw2.conv, t)
             if join is not None:
                 join()
-            return fused_bn_act(z, self.pw2.bn, mask=_drop_mask(self.drop_path, x), r1=x, r2=adpt,
-                                r2_scale=self.gamma, sums=s2)
+            mask = _drop_mask(self.drop_path, x)
+            if next_bn is not None:
+                pair = fused_bn_act_next(z, self.pw2.bn, next_bn, mask=mask, r1=x, r2=adpt, r2_scale=self.gamma)
+                if pair is not None:
+                    return pair
+            y = fused_bn_act(z, self.pw2.bn, mask=mask, r1=x, r2=adpt, r2_scale=self.gamma, sums=s2)
+            return y if next_bn is None else (y, None)
+        assert pre_out is None and next_bn is None
         out = self.prelkb_bn(x)
         adpt = self.adapter(out) if self.test_id >= 0 else None
         out = self.pw2(self.lk_nonlinear(self.large_kernel(self.pw1(out))))
@@ -466,8 +496,19 @@ class RepLKNetStage(nn.Module):
             _mark_replay(self.blocks)
 
     def forward(self, x):
-        for blk in self.blocks:
-            x = blk(x)
+        if not (FUSE_BN and self.training and x.is_cuda):
+            for blk in self.blocks:
+                x = blk(x)
+            return x
+        # training on the HIP kernels: a block's last launch also computes the next block's first BatchNorm
+        # (fused_bn_act_next) where the one-launch channel kernels serve the shape
+        pre_out = None
+        for i, blk in enumerate(self.blocks):
+            nxt = self.blocks[i + 1] if i + 1 < len(self.blocks) else None
+            chain = nxt is not None and not (isinstance(blk, RepLKBlock) and not hasattr(blk.large_kernel, "small_conv")) \
+                and not (isinstance(nxt, RepLKBlock) and not hasattr(nxt.large_kernel, "small_conv"))
+            r = blk(x, pre_out, nxt.pre_bn if chain else None)
+            x, pre_out = r if isinstance(r, tuple) else (r, None)
         return x
 
 

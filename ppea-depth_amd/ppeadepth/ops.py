@@ -604,6 +604,65 @@ def bn_act_channel(z1, bn1, z2=None, bn2=None, mask=None, r1=None, r2=None, r2_s
                                mask, r1, r2, r2_scale, act, bn1.eps, bn1.momentum, skip)
 
 
+class _BnActChannelNext(torch.autograd.Function):
+    """End of one block + first BatchNorm of the next in one launch per direction (csrc/bn_fused.hip, bn_*_channel_next):
+    y = mask * BN_A(z) + r1 + s * r2,  y2 = BN_B(y).  Bit-identical to _BnActChannel(z, A, ...) followed by
+    _BnActChannel(y, B, skip=True)."""
+
+    @staticmethod
+    def forward(ctx, z, gA, bA, rmA, rvA, gB, bB, rmB, rvB, mask, r1, r2, r2_scale, eps, momentum):
+        z = z.contiguous()
+        N, C = z.shape[0], z.shape[1]
+        HW = z.numel() // (N * C)
+        dt = z.dtype
+        r1 = None if r1 is None else r1.contiguous().to(dt)
+        r2 = None if r2 is None else r2.contiguous().to(dt)
+        gAf, bAf = gA.detach().float().contiguous(), bA.detach().float().contiguous()
+        gBf, bBf = gB.detach().float().contiguous(), bB.detach().float().contiguous()
+        maskf = None if mask is None else mask.detach().reshape(-1).float().contiguous()
+        st = torch.empty(4, C, device=z.device, dtype=_F32)          # meanA | invstdA | meanB | invstdB
+        y, y2 = torch.empty_like(z), torch.empty_like(z)
+        call(f"ppea_bn_fwd_channel_next_{_suffix(z)}", ptr(z), _ptr_array((gAf, bAf, gBf, bBf)),
+             _ptr_array((rmA, rvA, rmB, rvB, st[0], st[1], st[2], st[3])), float(eps), float(momentum), ptr(maskf),
+             ptr(r1), ptr(r2), float(r2_scale), ptr(y), ptr(y2), N, C, HW, stream_ptr())
+        ctx.save_for_backward(z, y, st, gAf, bAf, gBf, bBf, maskf)
+        ctx.r2_scale = float(r2_scale)
+        ctx.has = (r1 is not None, r2 is not None)
+        ctx.pdt = (gA.dtype, bA.dtype, gB.dtype, bB.dtype)
+        ctx.mark_non_differentiable(st)
+        ctx.set_materialize_grads(False)
+        return y, y2, st
+
+    @staticmethod
+    def backward(ctx, dy, dy2, _dst):
+        z, y, st, gAf, bAf, gBf, bBf, maskf = ctx.saved_tensors
+        N, C = z.shape[0], z.shape[1]
+        HW = z.numel() // (N * C)
+        if dy2 is None:
+            dy2 = torch.zeros_like(z)
+        dy2 = dy2.contiguous().to(z.dtype)
+        dskip = None if dy is None else dy.contiguous().to(z.dtype)
+        sums = torch.empty(4, C, device=z.device, dtype=_F32)
+        dz, dyt = torch.empty_like(z), torch.empty_like(z)
+        stats = _stats_array((st[0], st[1], gAf, bAf, st[2], st[3], gBf, bBf))
+        call(f"ppea_bn_bwd_channel_next_{_suffix(z)}", ptr(dy2), ptr(dskip), ptr(z), ptr(y), stats, ptr(maskf),
+             1.0 / float(N * HW), ptr(dz), ptr(dyt), ptr(sums), N, C, HW, stream_ptr())
+        n = ctx.needs_input_grad
+        dgA = sums[1].to(ctx.pdt[0]) if n[1] else None
+        dbA = sums[0].to(ctx.pdt[1]) if n[2] else None
+        dgB = sums[3].to(ctx.pdt[2]) if n[5] else None
+        dbB = sums[2].to(ctx.pdt[3]) if n[6] else None
+        dr1 = dyt if ctx.has[0] else None
+        dr2 = (dyt if ctx.r2_scale == 1.0 else dyt * ctx.r2_scale) if ctx.has[1] else None
+        return (dz, dgA, dbA, None, None, dgB, dbB, None, None, None, dr1, dr2, None, None, None)
+
+
+def bn_act_channel_next(z, bnA, bnB, mask=None, r1=None, r2=None, r2_scale=1.0):
+    """-> (y, y2, stats [4,C] = meanA | invstdA | meanB | invstdB).  Updates the running statistics of both BNs."""
+    return _BnActChannelNext.apply(z, bnA.weight, bnA.bias, bnA.running_mean, bnA.running_var, bnB.weight, bnB.bias,
+                                   bnB.running_mean, bnB.running_var, mask, r1, r2, r2_scale, bnA.eps, bnA.momentum)
+
+
 def bn_act_apply(z1, g1, b1, mean1, invstd1, z2=None, g2=None, b2=None, mean2=None, invstd2=None, mask=None,
                  r1=None, r2=None, r2_scale=1.0, act=ACT_NONE, count=None, group=None):
     if count is None:

@@ -1015,3 +1015,83 @@ def test_dwconv_epilogue_sums_give_both_batchnorm_statistics(device, shape):
         yf = y.double()
         assert rel_err(mean.cpu(), yf.mean((0, 2, 3)).cpu()) < 1e-6
         assert rel_err(var.cpu(), yf.var((0, 2, 3), unbiased=False).cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_bn_channel_next_kernels_are_bit_identical_to_two_launches(device, dtype):
+    """Kernel level, both dtypes: y, y2 = bn_act_channel_next(z, A, B, mask, r1, r2) against bn_act_channel(z, A, ...)
+    followed by fused_bn_act(y, B, skip=True) -- outputs, every gradient (z, r1, r2, both BNs' affine parameters) and the
+    running statistics must agree BITWISE, with and without a gradient arriving at y through another consumer."""
+    from ppeadepth import ops
+    from ppeadepth.batchnorm import BatchNorm2d, fused_bn_act
+    shape = (5, 64, 6, 20)
+    g = _g(123)
+    dt = torch.float32 if dtype == "f32" else torch.bfloat16
+    z0 = (torch.randn(shape, generator=g) * 2 + 0.5).to(dt).to(device)
+    r10, r20 = torch.randn(shape, generator=g).to(dt).to(device), torch.randn(shape, generator=g).to(dt).to(device)
+    go2, goy = torch.randn(shape, generator=g).to(dt).to(device), torch.randn(shape, generator=g).to(dt).to(device)
+    mask = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25], device=device)
+    res = []
+    for merged in (False, True):
+        bnA, bnB = BatchNorm2d(64).to(device), BatchNorm2d(64).to(device)
+        with torch.no_grad():
+            bnA.weight.copy_(torch.rand(64, generator=_g(1)) + 0.5); bnA.bias.copy_(torch.randn(64, generator=_g(2)) * 0.2)
+            bnB.weight.copy_(torch.rand(64, generator=_g(3)) + 0.5); bnB.bias.copy_(torch.randn(64, generator=_g(4)) * 0.2)
+        z, r1, r2 = (t.clone().requires_grad_(True) for t in (z0, r10, r20))
+        if merged:
+            y, y2, _ = ops.bn_act_channel_next(z, bnA, bnB, mask=mask, r1=r1, r2=r2, r2_scale=0.5)
+            ys = y
+        else:
+            y, _ = ops.bn_act_channel(z, bnA, mask=mask, r1=r1, r2=r2, r2_scale=0.5)
+            y2, ys = fused_bn_act(y, bnB, skip=True)
+        ((y2 * go2).sum() + (ys * goy).sum()).backward()
+        res.append([y.detach(), y2.detach(), z.grad, r1.grad, r2.grad, bnA.weight.grad, bnA.bias.grad, bnB.weight.grad,
+                    bnB.bias.grad, bnA.running_mean, bnA.running_var, bnB.running_mean, bnB.running_var])
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), i
+
+
+def test_block_chain_last_bn_plus_next_pre_bn_is_bit_identical(device, dtype="bf16"):
+    """fused_bn_act_next: a block's last BatchNorm (+ DropPath + residual + adapter) and the next block's first BatchNorm
+    as ONE launch per direction.  A whole stage (2 RepLK + 2 ConvFFN blocks, DropPath on, adapters on) run with and
+    without the chaining must agree BITWISE: output, input gradient, every parameter gradient, every running statistic."""
+    from oracle import synth
+    from ppeadepth import batchnorm, rng
+    from ppeadepth.networks import replknet_adapter as rka
+    C, K, H, W, B = 128, 13, 12, 20, 3          # hidden = 32: the adapters run on the MFMA kernels (deterministic), not the library
+
+    def run(chain):
+        saved = batchnorm.BN_CHAIN
+        batchnorm.BN_CHAIN = chain
+        try:
+            st = rka.RepLKNetStage(C, 2, K, [0.1, 0.2], 5, adpt_test=4, ratio=0.25)
+            synth.fill_state_dict(st)
+            st = st.to(device).train()
+            for n, p in st.named_parameters():
+                p.requires_grad = "adapter" in n or ".bn" in n or "_bn" in n
+            g = _g(5)
+            x = torch.randn(B, C, H, W, generator=g).to(device).requires_grad_(True)
+            go = torch.randn(B, C, H, W, generator=g).to(device)
+            rng.set_mode("reference")
+            torch.manual_seed(11)
+            if dtype == "bf16":
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = st(x.bfloat16())
+                y.backward(go.bfloat16())
+            else:
+                y = st(x)
+                y.backward(go)
+            torch.cuda.synchronize()
+            grads = {n: p.grad for n, p in st.named_parameters() if p.grad is not None}
+            return y.detach(), x.grad, grads, {n: b.clone() for n, b in st.named_buffers()}
+        finally:
+            batchnorm.BN_CHAIN = saved
+            rng.set_mode("device")
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert a[2].keys() == b[2].keys() and len(a[2]) > 20
+    for n in a[2]:
+        assert torch.equal(a[2][n], b[2][n]), n
+    for n in a[3]:
+        assert torch.equal(a[3][n], b[3][n]), n
