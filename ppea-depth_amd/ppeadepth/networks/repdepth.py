@@ -32,6 +32,11 @@ POSE_ON_TEACHER_STREAM = _os.environ.get("PPEA_POSE_ON_SIDE", "0") == "1"
 # frame's pose (the cost volume) -- its backward then depends only on the loss and can run under the student's backward
 # instead of after it
 POSE_OWN_STREAM = _os.environ.get("PPEA_POSE_STREAM", "0") == "1"
+# adapters of the TEACHER on a side stream of their own as well.  A stream that first joins the capture from a stream that
+# was itself forked faulted in round 1 ("nested fork"); here the teacher's adapter stream is joined to the step stream at
+# the top of the step (star topology), so inside the teacher branch it only ever exchanges events with streams that
+# are already part of the capture.
+TEACHER_ADAPTER_STREAM = _os.environ.get("PPEA_TEACHER_ADAPTER_STREAM", "0") == "1"
 
 
 def _g(opt, name, default):
@@ -143,7 +148,8 @@ class RepDepth(nn.Module):
         if st is None or st.device != device:
             st = self._side = torch.cuda.Stream(device)
             from . import replknet_adapter
-            replknet_adapter.NO_FORK_ON.add(st.cuda_stream)      # no nested forks (HIP graph capture faults)
+            if not TEACHER_ADAPTER_STREAM:
+                replknet_adapter.NO_FORK_ON.add(st.cuda_stream)  # no nested forks (HIP graph capture faults)
         return st
 
     def predict_poses(self, inputs):
@@ -238,6 +244,10 @@ class RepDepth(nn.Module):
         if TWO_STREAMS and img_aug.is_cuda and self.training and not self.freeze_tp:
             side = self._side_stream(img_aug.device)
             side.wait_stream(torch.cuda.current_stream())
+            if TEACHER_ADAPTER_STREAM:
+                from . import replknet_adapter
+                ta = replknet_adapter.side_stream_of(side)
+                ta.wait_stream(torch.cuda.current_stream())      # joins the capture HERE, from the step stream
         try:
             pose_pred = None
             pose_join = None
@@ -326,6 +336,9 @@ class RepDepth(nn.Module):
             if side is not None:
                 main = torch.cuda.current_stream()
                 main.wait_stream(side)
+                if TEACHER_ADAPTER_STREAM:
+                    from . import replknet_adapter
+                    main.wait_stream(replknet_adapter.side_stream_of(side))
                 for v in mono_outputs.values():          # produced on the side stream, consumed on this one
                     if torch.is_tensor(v) and v.is_cuda:
                         v.record_stream(main)

@@ -38,14 +38,20 @@ _SIDE = {}
 NO_FORK_ON = set()       # cuda_stream handles on which adapters run inline (already a forked branch)
 
 
+def side_stream_of(main):
+    """The adapter side stream that belongs to `main` (created on first use)."""
+    key = (main.device.index, main.cuda_stream)
+    side = _SIDE.get(key)
+    if side is None:
+        side = _SIDE[key] = torch.cuda.Stream(main.device)
+    return side
+
+
 def _forked_adapter(adapter, inp):
     """Run `adapter(inp)` on a side stream forked from the current one; returns (output, join) where join()
     must be called on the current stream before the output is consumed."""
     main = torch.cuda.current_stream()
-    key = (inp.device.index, main.cuda_stream)
-    side = _SIDE.get(key)
-    if side is None:
-        side = _SIDE[key] = torch.cuda.Stream(inp.device)
+    side = side_stream_of(main)
     side.wait_stream(main)
     # `inp` was allocated on `main` but the adapter SAVES it for backward, where side-stream kernels read it (the weight
     # gradient of D_fc1) right before autograd drops the last reference: without this mark the allocator hands the
