@@ -184,6 +184,32 @@ def main():
             replay_us[kind] = s_ev.elapsed_time(e_ev) / 20 * 1e3
     ops.PROFILE_REPLAY.clear()
     barrier()
+    # second roofline: the kernel family that carries the most wall time of the step (profiles/r02_wall_attribution.txt) --
+    # the NCHW 1x1-conv GEMM, on its largest stage-2 shape (ConvFFN pw1, 512 -> 2048 at 12x40, the batch of this run);
+    # 20 launches back to back between two HIP events on the launch stream
+    pw_roof = None
+    if args.dtype == "bf16" and args.rep_size == "b" and rank == 0:
+        with torch.cuda.stream(engine.stream):
+            xx = torch.randn(B, 512, 12, 40, device=device).bfloat16()
+            aa = (torch.randn(2048, 512, device=device) / 512 ** 0.5).bfloat16()
+            for _ in range(3):
+                ops.pwconv_raw(aa, xx)
+            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_ev.record()
+            for _ in range(20):
+                ops.pwconv_raw(aa, xx)
+            e_ev.record()
+            e_ev.synchronize()
+            t_pw = s_ev.elapsed_time(e_ev) / 20 * 1e-3
+        flops = 2.0 * B * 480 * 512 * 2048
+        pw_roof = {"kernel": "pwconv_kernel<128,2,2,0,false,32>: 1x1 conv 512 -> 2048 on [%d,512,12,40] (ConvFFN pw1, stage 2)" % B,
+                   "bound": "mfma", "achieved": round(flops / t_pw / 1e12, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                   "frac": round(flops / t_pw / 1e12 / MFMA_BF16_PEAK_TF, 4), "traffic": None,
+                   "back_to_back_us": round(t_pw * 1e6, 1), "flops_per_launch": flops,
+                   "note": "host-paced launches: hipGraph-paced 23 us (profiles/r02_pwconv_shapes.txt); "
+                           "algorithmic bytes %.1f MB" % ((B * 480 * (512 + 2048) + 512 * 2048) * 2 / 1e6)}
+        del xx, aa
+    barrier()
     # Several ranks: the captured step also holds the RCCL calls (SyncBN all-gathers / all-reduces on per-branch
     # communicators, the gradient all-reduce on a side stream).  Capture is attempted on every rank; if any
     # rank fails, all fall back to eager launches (PPEA_MULTI_GRAPH=0 skips the attempt).
@@ -246,6 +272,7 @@ def main():
                        "launch": launch},
             "final_loss": round(loss_val, 5),
             "roofline": roof,
+            "roofline_pwconv": pw_roof,
         }
 
         return line
