@@ -106,6 +106,31 @@ def cpu_baseline(seconds_budget=40.0, eval_root=None):
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves, one per GPU, BEFORE anything touches a
+    GPU (torch.cuda.device_count() does not initialise HIP on this image), and leave with the worst exit status.  Never
+    benchmarks a configuration other than the one asked for: fewer visible devices than N is an error.
+    Reference launcher: `accelerate launch --multi_gpu` (train.py:39-42)."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {n_dev} HIP device(s) visible; refusing to run (and report) "
+                         f"a different configuration")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,7 +141,14 @@ def main():
     ap.add_argument("--rep_size", default="b", choices=["b", "l"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="no hipGraph: launch every kernel from Python")
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--dc", action="store_true",
+                    help="Stage-2 decoder adapter (BASELINE config 5: --dc after dc_ft_init, Cityscapes intrinsics; the "
+                         "reference trains it at 192x512, BASELINE names 512x1024: pass --height/--width)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)                # does not return
 
     from ppeadepth import dist as pdist
     from ppeadepth import networks, options, ops, rng
@@ -128,29 +160,30 @@ def main():
         on = os.environ["PPEA_STREAMS"] == "1"
         networks.repdepth.TWO_STREAMS = on
         networks.replknet_adapter.ADAPTER_STREAMS = on
-    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE {world} != --gpus {args.gpus}; refusing to report n_gpus != requested")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    H, W, B = 192, 640, args.batch
-    opt = options.default_options(height=H, width=W, batch_size=B, rep_size=args.rep_size)
+    H, W, B = args.height, args.width, args.batch
+    opt = options.default_options(height=H, width=W, batch_size=B, rep_size=args.rep_size, dc=args.dc)
     torch.manual_seed(0)
     model = networks.RepDepth(opt)
+    if args.dc:
+        model.dc_ft_init()                       # reference Trainer.__init__, trainer.py:158-161
     synth.fill_state_dict(model)                 # deterministic random-init weights (no checkpoints offline)
     model.to(device).train()
-    if os.environ.get("PPEA_EXPERIMENT_FREEZE_POSE") == "1":   # what-if probe (which branch is critical), not a benchmark mode
-        model.freeze_pose_net()
     pdist.broadcast_module(model)
     if pdist.collectives_on():
-        from ppeadepth import batchnorm
-        batchnorm.assign_groups(model)           # teacher / student SyncBN exchanges on separate communicators
+        pdist.assign_groups(model)               # one communicator per branch (stream) of the step
     amp = torch.bfloat16 if args.dtype == "bf16" else None
     trainer = Trainer(opt, model, device, amp_dtype=amp)
     engine = pdist.TrainEngine(trainer, bf16_params=(args.dtype == "bf16"))
     rng.set_mode("device")
-    inputs = {k: v.to(device) for k, v in synth.make_inputs(B, H, W, seed=1234 + rank, smooth=True).items()}
+    inputs = {k: v.to(device) for k, v in synth.make_inputs(B, H, W, seed=1234 + rank, smooth=True,
+                                                            intrinsics="cityscapes" if args.dc else "kitti").items()}
     random.seed(1000 + rank)
 
     def barrier():
@@ -165,9 +198,11 @@ def main():
     # roofline probe: HIP events around every k=31 launch of ONE eager step (events cannot be recorded
     # inside a captured graph); the same kernels with the same arguments are what the graph replays.
     ops.PROFILE_DWCONV = []                       # (kind, start_event, end_event) per k=31 launch
+    ops.SYNC_COUNTERS = {}                        # SyncBN launches / collectives of this one eager step
     engine.step(dict(inputs))
     barrier()
     events, ops.PROFILE_DWCONV = ops.PROFILE_DWCONV, None
+    sync_counts, ops.SYNC_COUNTERS = ops.SYNC_COUNTERS, None
     # the same launch (same tensors, same stream) 20x back to back between two HIP events: the kernel's duration
     # without the host gaps that events around ONE ~80 us launch include
     replay_us = {}
@@ -188,7 +223,7 @@ def main():
     # the NCHW 1x1-conv GEMM, on its largest stage-2 shape (ConvFFN pw1, 512 -> 2048 at 12x40, the batch of this run);
     # 20 launches back to back between two HIP events on the launch stream
     pw_roof = None
-    if args.dtype == "bf16" and args.rep_size == "b" and rank == 0:
+    if args.dtype == "bf16" and args.rep_size == "b" and rank == 0 and (H, W) == (192, 640):
         with torch.cuda.stream(engine.stream):
             xx = torch.randn(B, 512, 12, 40, device=device).bfloat16()
             aa = (torch.randn(2048, 512, device=device) / 512 ** 0.5).bfloat16()
@@ -223,10 +258,10 @@ def main():
         if fwd:
             t_k = sum(fwd) / len(fwd)       # events around each launch inside a step: what rocprofv3 reports for
             #                                 the same command (kernel average over the run) agrees within ~1-2 %
-            plane = B * C0 * 48 * 160
+            plane = B * C0 * (H // 4) * (W // 4)
             bytes_alg = plane * es * 3 + C0 * (961 + 25) * 4            # x in, y_big + y_small out, weights
             useful = 2.0 * plane * (961 + 25)
-            roof = {"kernel": "31x31 depthwise conv fwd (+ fused 5x5 branch), stage-0 planes [%d,%d,48,160]" % (B, C0),
+            roof = {"kernel": "31x31 depthwise conv fwd (+ fused 5x5 branch), stage-0 planes [%d,%d,%d,%d]" % (B, C0, H // 4, W // 4),
                     "bound": "hbm", "achieved": round(bytes_alg / t_k / 1e9, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(bytes_alg / t_k / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_launch_us": round(t_k * 1e6, 1), "launches_timed": len(fwd),
@@ -244,7 +279,7 @@ def main():
                              "mfma_useful_tflops": round(useful / t_k / 1e12, 1),
                              "mfma_peak_tflops": MFMA_BF16_PEAK_TF,
                              "mfma_frac": round(executed / t_k / 1e12 / MFMA_BF16_PEAK_TF, 3)})
-                if B == 12 and C0 == 128:
+                if B == 12 and C0 == 128 and (H, W) == (192, 640):
                     # HBM-side bytes per launch: parsed from the committed PMC summary (separate rocprofv3 --pmc
                     # FETCH_SIZE / WRITE_SIZE passes over tools/pmc_target.py, same shape; KB per dispatch;
                     # FETCH_SIZE doubled for 16-byte-per-lane loads on gfx950 as MI355X_MICROARCH.md prescribes)
@@ -259,18 +294,21 @@ def main():
                              "valu_tflops": round(useful / t_k / 1e12, 1),
                              "valu_frac": round(useful / t_k / 1e12 / VALU_PEAK_TF, 3)})
         line = {
-            "metric": "training img/s at 640x192 RepLKNet-31B" if args.rep_size == "b" else
-                      "training img/s at 640x192 RepLKNet-31L",
+            "metric": f"training img/s at {W}x{H} RepLKNet-31{args.rep_size.upper()}" + (" Stage-2 (--dc)" if args.dc else ""),
             "value": round(world * B * args.steps / dt, 3), "unit": "img/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic (smoothed uniform frames, KITTI intrinsics; random-init weights)",
-            "config": {"workload": f"RepLKNet-31{args.rep_size.upper()} Stage-1 640x192, {B} frame triplets/GPU, "
+            "config": {"workload": f"RepLKNet-31{args.rep_size.upper()} Stage-{2 if args.dc else 1}{' decoder adapter' if args.dc else ''} {W}x{H}, {B} frame triplets/GPU, "
                                    "process_batch + backward + grad all-reduce + Adam",
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "use_checkpoint": "BN-stat replay, no recompute (288 GB HBM)",
                        "launch": launch},
             "final_loss": round(loss_val, 5),
+            "sync_bn": ({"launches_per_step": sync_counts.get("launches", 0),
+                         "collectives_per_step": sync_counts.get("collectives", 0),
+                         "forced_single_rank": bool(pdist.FORCE_COLLECTIVES and world == 1)}
+                        if pdist.collectives_on() else None),
             "roofline": roof,
             "roofline_pwconv": pw_roof,
         }
@@ -334,7 +372,7 @@ def main():
         line = make_line(dt, loss_val, launch)
         if hang:
             line["hang"] = True
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and (H, W) == (192, 640) and not args.dc:
             import tempfile
             eval_root = tempfile.mkdtemp(prefix="ppea_eval_") if args.rep_size == "b" else None
             try:

@@ -1,0 +1,78 @@
+// Shared helpers of the BatchNorm kernels (bn_fused.hip: one rank; bn_sync.hip: SyncBN across ranks).
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int V = 8;         // elements per thread per step on the 16-byte path
+constexpr int CH_VECS = 8;   // 16-byte vectors per thread of a channel-owning workgroup: N * HW <= 256 * 8 * 8 = 16384 elements
+constexpr long CHANNEL_ELEMS = 16384;
+
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&o)[V]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o)[V]) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8<uint16_t>(const uint16_t* p, float (&o)[V]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        o[2 * k] = __uint_as_float(w[k] << 16);
+        o[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
+    }
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[V]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[V]) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void st8<uint16_t>(uint16_t* p, const float (&v)[V]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t lo = __builtin_bit_cast(uint16_t, (__bf16)v[2 * k]);
+        const uint32_t hi = __builtin_bit_cast(uint16_t, (__bf16)v[2 * k + 1]);
+        w[k] = lo | (hi << 16);
+    }
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// value a store of T would keep (bf16: round to nearest even; fp32: unchanged)
+template <typename T> __device__ __forceinline__ float round_as(float v);
+template <> __device__ __forceinline__ float round_as<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_as<uint16_t>(float v) { return __uint_as_float((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v) << 16); }
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+struct Branch {
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+};
+
+__device__ __forceinline__ float act_fwd(float u, int act) {
+    if (act == 1) return fmaxf(u, 0.f);
+    if (act == 2) return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
+    return u;
+}
+__device__ __forceinline__ float act_bwd(float u, int act) {
+    if (act == 1) return u > 0.f ? 1.f : 0.f;
+    if (act == 2) {
+        const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
+        const float pdf = 0.39894228040143268f * expf(-0.5f * u * u);
+        return cdf + u * pdf;
+    }
+    return 1.f;
+}
+
+}  // namespace

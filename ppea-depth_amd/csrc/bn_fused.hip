@@ -9,56 +9,9 @@
 //   backward: bn_bwd_reduce (per-plane sums of g and g*zhat) -> bn_bwd_finalize -> bn_bwd_apply.
 // Statistics are combined with Chan's parallel-variance formula (per-plane two-pass sums), so there
 // is no E[x^2] - mean^2 cancellation.  Layout NCHW, T = float or bf16 (fp32 math).
-#include "common.h"
+#include "bn_common.h"
 
 namespace {
-
-constexpr int TPB = 256;
-constexpr int V = 8;         // elements per thread per step on the 16-byte path
-
-template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&o)[V]);
-template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o)[V]) {
-    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
-    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-}
-template <> __device__ __forceinline__ void ld8<uint16_t>(const uint16_t* p, float (&o)[V]) {
-    const uint4 a = *reinterpret_cast<const uint4*>(p);
-    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        o[2 * k] = __uint_as_float(w[k] << 16);
-        o[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u);
-    }
-}
-template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[V]);
-template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[V]) {
-    reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
-    reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
-}
-template <> __device__ __forceinline__ void st8<uint16_t>(uint16_t* p, const float (&v)[V]) {
-    uint32_t w[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t lo = __builtin_bit_cast(uint16_t, (__bf16)v[2 * k]);
-        const uint32_t hi = __builtin_bit_cast(uint16_t, (__bf16)v[2 * k + 1]);
-        w[k] = lo | (hi << 16);
-    }
-    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// value a store of T would keep (bf16: round to nearest even; fp32: unchanged)
-template <typename T> __device__ __forceinline__ float round_as(float v);
-template <> __device__ __forceinline__ float round_as<float>(float v) { return v; }
-template <> __device__ __forceinline__ float round_as<uint16_t>(float v) { return __uint_as_float((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v) << 16); }
-
-__device__ __forceinline__ float block_sum(float v, float* red) {
-    v = wave_sum(v);
-    const int wave = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[wave] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
 
 // partial[(c*N + n)*2 + {0,1}] = (mean, M2) of plane (n, c)
 template <typename T>
@@ -199,28 +152,6 @@ __global__ void bn_sync_combine(const float* __restrict__ gathered, int world, i
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / fmaxf(total - 1.f, 1.f));
     }
-}
-
-struct Branch {
-    const float* mean;
-    const float* invstd;
-    const float* gamma;
-    const float* beta;
-};
-
-__device__ __forceinline__ float act_fwd(float u, int act) {
-    if (act == 1) return fmaxf(u, 0.f);
-    if (act == 2) return 0.5f * u * (1.f + erff(u * 0.70710678118654752f));
-    return u;
-}
-__device__ __forceinline__ float act_bwd(float u, int act) {
-    if (act == 1) return u > 0.f ? 1.f : 0.f;
-    if (act == 2) {
-        const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
-        const float pdf = 0.39894228040143268f * expf(-0.5f * u * u);
-        return cdf + u * pdf;
-    }
-    return 1.f;
 }
 
 // one block per (plane, chunk); VEC elements per thread per iteration
@@ -448,7 +379,6 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_wave(const T* __restrict__ 
 // ---- small channels (N*HW <= 16384 elements): one WORKGROUP per CHANNEL covers all N planes, so the statistics
 // are final when it is done -- no partial buffer, no finalize launch (stages 2 and 3 of the trunk: 20 of
 // the 24 blocks of each encoder).
-constexpr int CH_VECS = 8;                   // 16-byte vectors per thread: N * HW <= 256 * 8 * 8 = 16384 elements
 
 template <typename T>
 __global__ __launch_bounds__(TPB) void bn_stats_channel(const T* __restrict__ z, int N, int C, int HW, float eps,
@@ -880,7 +810,6 @@ __global__ __launch_bounds__(TPB) void bn_bwd_channel_next(const T* __restrict__
     }
 }
 
-constexpr long CHANNEL_ELEMS = 16384;       // N * HW up to here: the wave-per-channel kernels
 
 // ---- flat element-wise passes (HW % 8 == 0): 8 elements per thread, channel looked up per thread -------
 template <typename T>
@@ -928,8 +857,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_flat(const T* __restrict__ d
                                                          const T* __restrict__ z2, Branch b1, Branch b2,
                                                          const float* __restrict__ mask,
                                                          const float* __restrict__ sums, float inv_count,
-                                                         T* __restrict__ dz1, T* __restrict__ dz2, int act, int C,
-                                                         int HW, long total8) {
+                                                         const T* __restrict__ acc, T* __restrict__ dz1,
+                                                         T* __restrict__ dz2, int act, int C, int HW, long total8) {
     const long t = (long)blockIdx.x * TPB + threadIdx.x;
     if (t >= total8) return;
     const long i = t * V;
@@ -961,6 +890,12 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_flat(const T* __restrict__ d
         const float g = d[k] * m * act_bwd(u, act);
         o1v[k] = a1 * (g - mg - (x1[k] - mu1) * is1 * m1);
         o2v[k] = a2 * (g - mg - (xx2 - mu2) * is2 * m2);
+    }
+    if (acc != nullptr) {                                  // gradient reaching z1 through its other consumer (as bn_bwd_channel)
+        float ea[V];
+        ld8<T>(acc + i, ea);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o1v[k] = round_as<T>(o1v[k]) + ea[k];
     }
     st8<T>(dz1 + i, o1v);
     if (z2 != nullptr) st8<T>(dz2 + i, o2v);
@@ -1026,16 +961,17 @@ int bwd_reduce_impl(const void* dy, const void* z1, const void* z2, const float*
 template <typename T>
 int bwd_apply_impl(const void* dy, const void* z1, const void* z2, const float* const* st, const float* mask,
                    const float* sums, float inv_count, void* dz1, void* dz2, int act, int N, int C, int HW,
-                   void* stream) {
+                   void* stream, const void* acc = nullptr) {
     if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return PPEA_ERR_UNSUPPORTED;
     const Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
     if (HW % V == 0) {
         const long total8 = (long)N * C * HW / V;
         hipLaunchKernelGGL(bn_bwd_apply_flat<T>, dim3((unsigned)((total8 + TPB - 1) / TPB)), dim3(TPB), 0,
                            (hipStream_t)stream, (const T*)dy, (const T*)z1, (const T*)z2, b1, b2, mask, sums,
-                           inv_count, (T*)dz1, (T*)dz2, act, C, HW, total8);
+                           inv_count, (const T*)acc, (T*)dz1, (T*)dz2, act, C, HW, total8);
         return launch_status();
     }
+    if (acc != nullptr) return PPEA_ERR_UNSUPPORTED;
     const int chunks = plane_chunks((long)N * C, HW);
     hipLaunchKernelGGL(bn_bwd_apply<T>, dim3((unsigned)((long)N * C * chunks)), dim3(TPB), 0, (hipStream_t)stream,
                        (const T*)dy, (const T*)z1, (const T*)z2, b1, b2, mask, sums, inv_count, (T*)dz1, (T*)dz2, act,
@@ -1264,6 +1200,18 @@ int ppea_bn_bwd_apply_bf16(const void* dy, const void* z1, const void* z2, const
                            const float* mask, const float* sums, float inv_count, void* dz1, void* dz2, int act,
                            int N, int C, int HW, void* stream) {
     return bwd_apply_impl<uint16_t>(dy, z1, z2, stats, mask, sums, inv_count, dz1, dz2, act, N, C, HW, stream);
+}
+// ... with `acc` (same shape as z1, or NULL): dz1 = round(dz1) + acc, the gradient that reaches z1 through its other consumer
+// (a block's residual connection) -- what ppea_bn_bwd_channel_* does in the one-launch form.  HW % 8 == 0.
+int ppea_bn_bwd_apply_acc_f32(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                              const float* mask, const float* sums, float inv_count, const void* acc, void* dz1, void* dz2,
+                              int act, int N, int C, int HW, void* stream) {
+    return bwd_apply_impl<float>(dy, z1, z2, stats, mask, sums, inv_count, dz1, dz2, act, N, C, HW, stream, acc);
+}
+int ppea_bn_bwd_apply_acc_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                               const float* mask, const float* sums, float inv_count, const void* acc, void* dz1, void* dz2,
+                               int act, int N, int C, int HW, void* stream) {
+    return bwd_apply_impl<uint16_t>(dy, z1, z2, stats, mask, sums, inv_count, dz1, dz2, act, N, C, HW, stream, acc);
 }
 
 }  // extern "C"

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libppea_depth.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -83,6 +83,14 @@ SIGNATURES = {
     "ppea_bn_bwd_finalize_f32": [_vp, _i, _i, _vp, _vp],
     "ppea_bn_bwd_apply_f32": [_vp] * 6 + [_f, _vp, _vp] + [_i] * 4 + [_vp],
     "ppea_bn_bwd_apply_bf16": [_vp] * 6 + [_f, _vp, _vp] + [_i] * 4 + [_vp],
+    "ppea_bn_bwd_apply_acc_f32": [_vp] * 6 + [_f, _vp, _vp, _vp] + [_i] * 4 + [_vp],
+    "ppea_bn_bwd_apply_acc_bf16": [_vp] * 6 + [_f, _vp, _vp, _vp] + [_i] * 4 + [_vp],
+    "ppea_bn_sync_stats_workspace_bytes": [_i] * 4,
+    "ppea_bn_sync_stats_f32": [_vp] * 4 + [_i] * 3 + [_vp],
+    "ppea_bn_sync_stats_bf16": [_vp] * 4 + [_i] * 3 + [_vp],
+    "ppea_bn_sync_stats_from_sums_f32": [_vp, _i, _i, _l, _vp, _vp],
+    "ppea_bn_sync_apply_f32": [_vp, _vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _vp, _vp] + [_i] * 4 + [_vp],
+    "ppea_bn_sync_apply_bf16": [_vp, _vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _vp, _vp] + [_i] * 4 + [_vp],
     "ppea_reflect_pad1_fwd_f32": [_vp, _vp, _l, _i, _i, _vp],
     "ppea_reflect_pad1_fwd_bf16": [_vp, _vp, _l, _i, _i, _vp],
     "ppea_reflect_pad1_bwd_f32": [_vp, _vp, _l, _i, _i, _vp],

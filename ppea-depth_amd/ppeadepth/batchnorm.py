@@ -6,10 +6,14 @@ reset) -- batch statistics over the GLOBAL batch (all ranks), running stats upda
 momentum 0.1 and the unbiased variance.  `state_dict` keys are those of nn.BatchNorm2d.
 
 MI355X design notes
-  * one rank: `torch.native_batch_norm` (a single fused kernel each way);
-  * several ranks: local (mean, invstd) -> ONE flat all-gather of [mean | invstd | count]
-    per BN over RCCL -> combine -> element-wise apply; backward all-reduces
-    [sum_dy | sum_dy_xmu] (same collectives as torch's SyncBatchNorm, so numerics match);
+  * one rank: BN (+ activation, DropPath, residual, adapter add) is ONE launch per direction where a
+    workgroup can own a channel (`ops.bn_act_channel`), statistics + apply launches otherwise;
+  * several ranks: the SAME fused kernels split at the one point where ranks must talk -- local
+    statistics in wire format [mean | biased var | count] (one launch, or none: the previous
+    BatchNorm's apply launch / the producing GEMM's epilogue left them) -> ONE all-gather over RCCL
+    -> Chan combine + running statistics + apply in one launch (`ops.sync_bn_act`, csrc/bn_sync.hip);
+    backward: reduce -> ONE all-reduce of [sum_dy | sum_dy_xmu] -> apply.  Same collectives and
+    combine arithmetic as torch's SyncBatchNorm, so numerics match;
   * `--use_checkpoint` in the reference re-runs every block in backward (reentrant
     checkpoint), which updates the running statistics of the BNs inside a second time with the
     same batch statistics.  With 288 GB of HBM this build never recomputes activations; the
@@ -169,6 +173,33 @@ def _global_stats_pair(bn1, z1, bn2, z2, sums=None):
     return out[0], out[1]
 
 
+SYNC_FUSED = __import__("os").environ.get("PPEA_SYNC_FUSED", "1") == "1"     # 0: the round-2 multi-rank path (A/B only)
+
+
+def _sync_path_ok(z, bns):
+    """Several ranks and every BN of the call is a SyncBN on one communicator: the fused two-launch form applies."""
+    from . import ops
+    if not (SYNC_FUSED and _collectives_on() and all(bn.sync and bn.training for bn in bns)):
+        return False
+    g0 = getattr(bns[0], "group", None)
+    return (all(getattr(bn, "group", None) is g0 and bn.eps == bns[0].eps and bn.momentum == bns[0].momentum
+                and bn.running_mean.dtype == torch.float32 for bn in bns) and ops.sync_bn_supported(z))
+
+
+def _book_sync(bns, st, z):
+    """num_batches_tracked / checkpoint-replay bookkeeping of a sync_bn_act call (st = mean1 | invstd1 | mean2 | invstd2)."""
+    group = getattr(bns[0][1], "group", None)
+    from . import ops
+    cnt = float(z.numel() // z.shape[1] * ops.sync_world(group))
+    for k, (_, bn) in enumerate(bns):
+        if _ACTIVE_DEFERRED is None:
+            bn.num_batches_tracked += 1
+        else:
+            _ACTIVE_DEFERRED.count(bn)
+            if bn.replay_update and torch.is_grad_enabled():
+                _ACTIVE_DEFERRED.add(bn, st[2 * k], st[2 * k + 1], cnt)
+
+
 def assign_groups(model):
     """One process group per concurrently running branch: ProcessGroupNCCL runs a group's collectives in order
     on one internal stream, so the teacher's and the student's SyncBN exchanges must not share a group or the
@@ -197,6 +228,13 @@ def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None,
     from . import ops
     assert bn1.training, "fused_bn_act is the training-mode path; eval goes through BatchNorm2d.forward"
     bns = [(z1, bn1)] + ([(z2, bn2)] if z2 is not None else [])
+    if _sync_path_ok(z1, [bn for _, bn in bns]):
+        # several ranks: [statistics launch] -> all-gather -> combine + apply launch (same fused neighbours as below)
+        want_skip = bool(skip and torch.is_grad_enabled() and z1.requires_grad)
+        outs = ops.sync_bn_act(z1, bn1, z2, bn2, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act,
+                               group=getattr(bn1, "group", None), sums=sums, skip=want_skip)
+        _book_sync(bns, outs[1], z1)
+        return (outs[0], outs[2] if want_skip else z1) if skip else outs[0]
     # small channels on one rank: statistics, running-statistics update and apply in ONE launch (backward likewise)
     if (ops.bn_channel_ok(z1) and all(bn.training for _, bn in bns) and not any(bn.sync and _collectives_on() for _, bn in bns)
             and (bn2 is None or (bn2.eps == bn1.eps and bn2.momentum == bn1.momentum))
@@ -250,6 +288,16 @@ def fused_bn_act_next(z, bnA, bnB, mask=None, r1=None, r2=None, r2_scale=1.0):
     served by the one-launch channel kernels (the caller then runs the two BatchNorms separately).  Same numbers, running
     statistics and bookkeeping as fused_bn_act(z, bnA, ...) followed by fused_bn_act(y, bnB, skip=True)."""
     from . import ops
+    if (BN_CHAIN and ops.bn_channel_ok(z) and bnA.num_features == bnB.num_features and _sync_path_ok(z, [bnA, bnB])):
+        # several ranks: stats(z) -> gather -> [apply A + local statistics of y] -> gather -> apply B: the second
+        # BatchNorm needs no statistics launch, and its backward adds the residual use's gradient of y in its apply launch
+        group = getattr(bnA, "group", None)
+        y, stA, pk = ops.sync_bn_act(z, bnA, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, group=group, emit=True)
+        _book_sync([(z, bnA)], stA, z)
+        want_skip = bool(torch.is_grad_enabled() and y.requires_grad)
+        outs = ops.sync_bn_act(y, bnB, group=group, packed=pk, skip=want_skip)
+        _book_sync([(y, bnB)], outs[1], y)
+        return (outs[2] if want_skip else y), outs[0]
     if not (BN_CHAIN and ops.bn_channel_ok(z) and bnA.training and bnB.training
             and not ((bnA.sync or bnB.sync) and _collectives_on())
             and bnA.eps == bnB.eps and bnA.momentum == bnB.momentum

@@ -44,6 +44,33 @@ def init_distributed(backend=None):
     return rank, local_rank, world
 
 
+# One communicator per concurrently running branch of the step (ProcessGroupNCCL orders a group's collectives on one
+# internal stream; RCCL communicators used from several streams at once need a consistent order on every rank).  Every
+# stream of the step therefore talks through exactly ONE communicator, and no communicator is used from two streams:
+#   step stream    (student trunk SyncBN, decoders, pose network, leftovers after backward) -> COMM["encoder"]
+#   teacher stream (teacher SyncBN, teacher decoder / adapters)                            -> COMM["mono_encoder"]
+#   adapter stream (student adapters' gradients)                                           -> COMM["adapters"]
+COMM = {}
+_COMM_OF_BRANCH = {"depth": "encoder", "encoder": "encoder", "pose": "encoder", "mono_depth": "mono_encoder",
+                   "mono_encoder": "mono_encoder", "encoder_adapters": "adapters"}
+
+
+def assign_groups(model):
+    """Create the per-branch communicators (RCCL only; gloo serialises on the host anyway) and hand the SyncBN layers
+    theirs.  Call on every rank, after init_process_group, before the first step."""
+    from . import batchnorm
+    COMM.clear()
+    groups = batchnorm.assign_groups(model)
+    if groups:
+        COMM.update(groups)
+        COMM["adapters"] = dist.new_group()
+    return COMM
+
+
+def comm_of(branch):
+    return COMM.get(_COMM_OF_BRANCH.get(branch, "encoder"))
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -140,6 +167,7 @@ class FlatGrads:
                 ranges.append((start, i))
                 start = i
         self._ranges = ranges
+        self._range_branch = [groups[a] for a, _ in ranges]        # branch name (or chunk index) of each range
         self._range_of = [k for k, (a, b) in enumerate(ranges) for _ in range(a, b)]
         self._active = False
         self._launched = [True] * len(ranges)
@@ -168,7 +196,7 @@ class FlatGrads:
             self._launch_range(k)              # in line, on the stream that produced every gradient of the range
 
     @torch.no_grad()
-    def _launch_range(self, k):
+    def _launch_range(self, k, after_backward=False):
         self._launched[k] = True
         a, b = self._ranges[k]
         groups = {}
@@ -186,7 +214,8 @@ class FlatGrads:
         hi = self.offsets[b] if b < len(self.offsets) else self.numel
         if collectives_on():
             chunk = self.flat[lo:hi]
-            dist.all_reduce(chunk)
+            # from a hook: the communicator of the stream that produced the range; after backward: the step stream's
+            dist.all_reduce(chunk, group=comm_of("encoder" if after_backward else self._range_branch[k]))
             chunk.mul_(1.0 / world_size())
 
     def finish(self):
@@ -197,7 +226,7 @@ class FlatGrads:
             hi = self.offsets[b] if b < len(self.offsets) else self.numel
             self.last_plan.append((a, b - a, hi - self.offsets[a], bool(self._launched[k])))
             if not self._launched[k]:
-                self._launch_range(k)
+                self._launch_range(k, after_backward=True)
         self._active = False
         for t, v in zip(self.targets, self.views):
             t.grad = v
@@ -387,29 +416,36 @@ class TrainEngine:
         snap = self.snapshot() if restore_state else None
         self.static_inputs = {k: v.clone() for k, v in inputs.items()}
         B = self.static_inputs[("color", 0, 0)].shape[0]
-        rng.set_aug_buffer(torch.zeros(B, device=dev))
+        # the augmentation-draw buffer and the recorded draw plan belong to THIS engine; they are installed in `rng` only
+        # while this method runs (eager steps after a capture, and other engines, draw afresh)
+        self._aug = torch.zeros(B, device=dev)
+        self._rng_plan = None
+        rng.set_aug_buffer(self._aug)
         reference_rng = rng.get_mode() == "reference"
         warmup = max(int(warmup), 1)
         import gc
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            for i in range(warmup):
-                rng.refill_aug_buffer()
-                if reference_rng and i == warmup - 1:
-                    rng.static_begin_record()      # this step's host draws become the graph's static draw buffers
-                self._step_body(dict(self.static_inputs))
-                if reference_rng and i == warmup - 1:
-                    rng.static_end_record()
-        torch.cuda.synchronize()
-        gc.collect()                        # drop autograd graphs of earlier steps before capturing
-        self.graph = torch.cuda.CUDAGraph()
-        rng.refill_aug_buffer()
-        rng.static_rewind()
-        torch.cuda.synchronize()
-        # the dict the captured step saw: process_batch adds ("relative_pose", f) entries to it (repdepth.py:507)
-        self.static_step_inputs = dict(self.static_inputs)
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            outputs, losses = self._step_body(self.static_step_inputs)
+        try:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                for i in range(warmup):
+                    rng.refill_aug(self._aug)
+                    if reference_rng and i == warmup - 1:
+                        rng.static_begin_record()      # this step's host draws become the graph's static draw buffers
+                    self._step_body(dict(self.static_inputs))
+                    if reference_rng and i == warmup - 1:
+                        self._rng_plan = rng.static_end_record()
+            torch.cuda.synchronize()
+            gc.collect()                        # drop autograd graphs of earlier steps before capturing
+            self.graph = torch.cuda.CUDAGraph()
+            rng.refill_aug(self._aug)
+            torch.cuda.synchronize()
+            # the dict the captured step saw: process_batch adds ("relative_pose", f) entries to it (repdepth.py:507)
+            self.static_step_inputs = dict(self.static_inputs)
+            with rng.serving(self._rng_plan):
+                with torch.cuda.graph(self.graph, stream=self.stream):
+                    outputs, losses = self._step_body(self.static_step_inputs)
+        finally:
+            rng.set_aug_buffer(None)
         self.static_out = (outputs, losses)
         if snap is not None:
             self.restore(snap)
@@ -466,8 +502,8 @@ class TrainEngine:
                         self.static_inputs[k].copy_(v, non_blocking=True)
                         if v.is_cuda:
                             v.record_stream(self.stream)
-            rng.refill_aug_buffer()
-            rng.refill_static()             # reference-order DropPath / tie-break draws (no-op in device mode)
+            rng.refill_aug(self._aug)
+            rng.refill_plan(self._rng_plan)  # reference-order DropPath / tie-break draws (None in device mode)
             self.graph.replay()
         cur.wait_stream(self.stream)
         self.trainer.step += 1

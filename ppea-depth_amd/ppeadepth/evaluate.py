@@ -49,6 +49,11 @@ def evaluate_image(pred_disp, gt_depth, eval_split="eigen", median_scaling=True,
     """One validation image (trainer.py:780-835): `pred_disp` [h,w] is the scaled disparity of
     `disp_to_depth(disp, 1e-3, 80)`; returns (the 7 errors, median ratio or None)."""
     gt_height, gt_width = gt_depth.shape[:2]
+    if eval_split == "cityscapes":
+        # the bottom 25 % (ego car) is cut off the ground truth first -- the loader did the same to the frames
+        # (trainer.py:775-778); the prediction is resized to the CROPPED height
+        gt_height = int(round(gt_height * 0.75))
+        gt_depth = gt_depth[:gt_height]
     pred_depth = 1 / resize_linear(pred_disp, gt_width, gt_height)
     if eval_split == "cityscapes":
         gt_depth = gt_depth[256:, 192:1856]
@@ -69,8 +74,8 @@ def evaluate_image(pred_disp, gt_depth, eval_split="eigen", median_scaling=True,
     return compute_errors(gt_depth, pred_depth), ratio
 
 
-def evaluate_disps(pred_disps, gt_depths, eval_split="eigen", median_scaling=True):
+def evaluate_disps(pred_disps, gt_depths, eval_split="eigen", median_scaling=True, pred_depth_scale_factor=1.0):
     """Mean of the 7 errors over a split (trainer.py:843)."""
-    errors = [evaluate_image(pred_disps[i], gt_depths[i], eval_split, median_scaling)[0]
+    errors = [evaluate_image(pred_disps[i], gt_depths[i], eval_split, median_scaling, pred_depth_scale_factor)[0]
               for i in range(len(pred_disps))]
     return np.array(errors).mean(0)

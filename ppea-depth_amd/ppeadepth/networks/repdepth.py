@@ -26,18 +26,6 @@ _ENC_CH = {"b": [128, 256, 512, 1024], "l": [192, 384, 768, 1536]}
 TWO_STREAMS = True
 BATCHED_POSES = True      # third (no_grad) pose pass replayed instead of recomputed (see _predict_poses_batched)
 POSE_ONE_BATCH = True      # both pairs as one 2B batch with per-pair BN statistics (needs the fused NHWC BN path)
-import os as _os
-POSE_ON_TEACHER_STREAM = _os.environ.get("PPEA_POSE_ON_SIDE", "0") == "1"
-# the pose network as a third parallel branch: forked at the start of the step, joined where the student needs the matching
-# frame's pose (the cost volume) -- its backward then depends only on the loss and can run under the student's backward
-# instead of after it
-POSE_OWN_STREAM = _os.environ.get("PPEA_POSE_STREAM", "0") == "1"
-# adapters of the TEACHER on a side stream of their own as well.  A stream that first joins the capture from a stream that
-# was itself forked faulted in round 1 ("nested fork"); here the teacher's adapter stream is joined to the step stream at
-# the top of the step (star topology), so inside the teacher branch it only ever exchanges events with streams that
-# are already part of the capture.
-TEACHER_ADAPTER_STREAM = _os.environ.get("PPEA_TEACHER_ADAPTER_STREAM", "0") == "1"
-
 
 def _g(opt, name, default):
     return getattr(opt, name, default)
@@ -148,8 +136,11 @@ class RepDepth(nn.Module):
         if st is None or st.device != device:
             st = self._side = torch.cuda.Stream(device)
             from . import replknet_adapter
-            if not TEACHER_ADAPTER_STREAM:
-                replknet_adapter.NO_FORK_ON.add(st.cuda_stream)  # no nested forks (HIP graph capture faults)
+            # The teacher's adapters run in line on this stream: forking them again would put event edges between two
+            # streams that are BOTH non-origin streams of the capture (teacher stream <-> its adapter stream), and HIP's
+            # stream capture faults on those (round 1: "nested fork"; round 2: rc 139 twice with a pre-joined adapter
+            # stream -- pre-joining changes where the stream enters the capture, not the side <-> adapter edges).
+            replknet_adapter.NO_FORK_ON.add(st.cuda_stream)
         return st
 
     def predict_poses(self, inputs):
@@ -244,48 +235,11 @@ class RepDepth(nn.Module):
         if TWO_STREAMS and img_aug.is_cuda and self.training and not self.freeze_tp:
             side = self._side_stream(img_aug.device)
             side.wait_stream(torch.cuda.current_stream())
-            if TEACHER_ADAPTER_STREAM:
-                from . import replknet_adapter
-                ta = replknet_adapter.side_stream_of(side)
-                ta.wait_stream(torch.cuda.current_stream())      # joins the capture HERE, from the step stream
         try:
-            pose_pred = None
-            pose_join = None
-            if side is not None and POSE_OWN_STREAM and not self.freeze_pose and not POSE_ON_TEACHER_STREAM:
-                main = torch.cuda.current_stream()
-                ps = getattr(self, "_pose_side", None)
-                if ps is None or ps.device != img_aug.device:
-                    ps = self._pose_side = torch.cuda.Stream(img_aug.device)
-                    from . import replknet_adapter
-                    replknet_adapter.NO_FORK_ON.add(ps.cuda_stream)
-                ps.wait_stream(main)
-                with torch.cuda.stream(ps):
-                    pose_pred = self.predict_poses(inputs)
-                    pose_ready = torch.cuda.Event()
-                    pose_ready.record(ps)
-
-                def pose_join(pose_pred=pose_pred, pose_ready=pose_ready, main=main):
-                    main.wait_event(pose_ready)
-                    for v in list(pose_pred.values()) + [inputs[("relative_pose", i)] for i in self.matching_ids[1:]]:
-                        v.record_stream(main)
             if side is not None:
                 with torch.cuda.stream(side):
-                    if POSE_ON_TEACHER_STREAM and not self.freeze_pose:
-                        # the teacher branch is the shorter one: the pose network (forward now, backward at the end of
-                        # the teacher's backward) rides on its stream; the student only waits for the pose of the
-                        # matching frame, which it needs at the cost volume
-                        pose_pred = self.predict_poses(inputs)
-                        pose_ready = torch.cuda.Event()
-                        pose_ready.record(side)
                     mono_outputs.update(self.mono_depth(self.mono_encoder(img_aug)))
-                if pose_pred is not None and pose_join is None:
-                    main = torch.cuda.current_stream()
-                    main.wait_event(pose_ready)
-                    for v in list(pose_pred.values()) + [inputs[("relative_pose", i)] for i in self.matching_ids[1:]]:
-                        v.record_stream(main)
-            if pose_pred is not None:
-                pass
-            elif not self.freeze_tp and not self.freeze_pose:
+            if not self.freeze_tp and not self.freeze_pose:
                 pose_pred = self.predict_poses(inputs)
             else:
                 with torch.no_grad():
@@ -308,10 +262,7 @@ class RepDepth(nn.Module):
             outputs["augmentation_mask"] = (static | nopose).float().reshape(B, 1, 1, 1)
 
             def relative_poses():
-                # evaluated by the matching encoder right before the cost volume: with the pose network on its own stream
-                # this is where the step waits for it (stem + stage 0 of both frames do not need the pose)
-                if pose_join is not None:
-                    pose_join()
+                # evaluated by the matching encoder right before the cost volume
                 rp = torch.stack([inputs[("relative_pose", i)] for i in self.matching_ids[1:]], 1)
                 return rp * (~nopose).to(rp.dtype)[:, None, None, None]
 
@@ -336,9 +287,6 @@ class RepDepth(nn.Module):
             if side is not None:
                 main = torch.cuda.current_stream()
                 main.wait_stream(side)
-                if TEACHER_ADAPTER_STREAM:
-                    from . import replknet_adapter
-                    main.wait_stream(replknet_adapter.side_stream_of(side))
                 for v in mono_outputs.values():          # produced on the side stream, consumed on this one
                     if torch.is_tensor(v) and v.is_cuda:
                         v.record_stream(main)

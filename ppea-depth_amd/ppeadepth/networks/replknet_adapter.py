@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops, rng
-from ..batchnorm import BatchNorm2d, _collectives_on, fused_bn_act, fused_bn_act_next
+from ..batchnorm import BatchNorm2d, fused_bn_act, fused_bn_act_next
 
 FUSE_BN = True      # training-mode BN + activation + residual glue on the fused HIP kernels
 ADAPTER_CHANNELS_LAST = True
@@ -165,7 +165,7 @@ class PointwiseConv(nn.Conv2d):
         apply launches (N * HW > 16 384: stages 0 / 1), the GEMM's epilogue also returns the per-channel partial sums
         that BatchNorm needs (`fused_bn_act(..., sums=sums)`)."""
         if (PW_MFMA and BN_SUMS and x.is_cuda and x.dtype == torch.bfloat16 and not self.weight.requires_grad
-                and x.shape[0] * x.shape[2] * x.shape[3] > 16384 and not _collectives_on()):   # SyncBN: packed local stats
+                and x.shape[0] * x.shape[2] * x.shape[3] > 16384):
             r = ops.pwconv_frozen(x, self.weight, want_sums=True)
             if r is not None:
                 return r
@@ -336,7 +336,6 @@ class ReparamLargeKernelConv(nn.Module):
         big, small = self.lkb_origin.conv, self.small_conv.conv
         if isinstance(big, LargeKernelDW) and small.kernel_size[0] in (3, 5) and small.stride[0] == 1:
             if (FUSE_BN and BN_SUMS and DW_SUMS and self.training and x.is_cuda and x.dtype == torch.bfloat16
-                    and not _collectives_on()
                     and x.shape[0] * x.shape[2] * x.shape[3] > 16384):
                 # stages 0 / 1: the conv's epilogue also leaves the per-channel sums the two BatchNorms need
                 y_big, y_small, sums = ops.dwconv_lk(x, big.weight, small.weight, want_sums=True)

@@ -498,12 +498,13 @@ class _BnAct(torch.autograd.Function):
             call("ppea_bn_bwd_finalize_f32", ptr(partial), N, C, ptr(sums), stream_ptr())
         elif err != 0:
             _abi.check(err, "ppea_bn_bwd_reduce_final")
-        if ctx.group is not None:                      # SyncBN: global sums (count is already global)
-            import torch.distributed as dist
-            dist.all_reduce(sums, group=ctx.group[0])
+        inv_count = 1.0 / ctx.count
+        if ctx.group is not None:                      # SyncBN: mean of the sums over ranks (ctx.count is the global count)
+            reduce_sums(sums, ctx.group[0])
+            inv_count *= sync_world(ctx.group[0])
         dz1 = torch.empty_like(z1)
         dz2 = None if z2 is None else torch.empty_like(z2)
-        call(f"ppea_bn_bwd_apply_{sfx}", ptr(dy), ptr(z1), ptr(z2), st, ptr(maskf), ptr(sums), 1.0 / ctx.count,
+        call(f"ppea_bn_bwd_apply_{sfx}", ptr(dy), ptr(z1), ptr(z2), st, ptr(maskf), ptr(sums), inv_count,
              ptr(dz1), ptr(dz2), ctx.act, N, C, HW, stream_ptr())
         dg1 = sums[1].to(ctx.pdt[0]) if ctx.needs_input_grad[1] else None
         db1 = sums[0].to(ctx.pdt[1]) if ctx.needs_input_grad[2] else None
@@ -661,6 +662,174 @@ def bn_act_channel_next(z, bnA, bnB, mask=None, r1=None, r2=None, r2_scale=1.0):
     """-> (y, y2, stats [4,C] = meanA | invstdA | meanB | invstdB).  Updates the running statistics of both BNs."""
     return _BnActChannelNext.apply(z, bnA.weight, bnA.bias, bnA.running_mean, bnA.running_var, bnB.weight, bnB.bias,
                                    bnB.running_mean, bnB.running_var, mask, r1, r2, r2_scale, bnA.eps, bnA.momentum)
+
+
+# ---------------------------------------------------------------------------------------------
+# A2 across ranks: SyncBatchNorm on the fused kernels (csrc/bn_sync.hip) -- two launches around ONE collective per
+# BatchNorm and direction                                                   networks/replknet_adapter.py:170-180
+# ---------------------------------------------------------------------------------------------
+SYNC_COUNTERS = None      # bench.py / tests: {"launches": n, "collectives": m} accumulated while set to a dict
+
+
+def _count(launches=0, collectives=0):
+    if SYNC_COUNTERS is not None:
+        SYNC_COUNTERS["launches"] = SYNC_COUNTERS.get("launches", 0) + launches
+        SYNC_COUNTERS["collectives"] = SYNC_COUNTERS.get("collectives", 0) + collectives
+
+
+def sync_bn_supported(z):
+    return (z.is_cuda and z.dim() == 4 and z.dtype in (_F32, _BF16) and (z.shape[2] * z.shape[3]) % 8 == 0)
+
+
+def sync_world(group):
+    import torch.distributed as dist
+    return dist.get_world_size(group)
+
+
+def gather_rows(packed, group):
+    """ONE all-gather of a rank's packed statistics -> [world, len(packed)]."""
+    import torch.distributed as dist
+    world = sync_world(group)
+    gathered = torch.empty(world, packed.numel(), device=packed.device, dtype=packed.dtype)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(gathered, packed, group=group)
+    else:
+        dist.all_gather(list(gathered.unbind(0)), packed, group=group)     # gloo has no tensor form
+    _count(collectives=1)
+    return gathered
+
+
+def reduce_sums(sums, group):
+    """ONE in-place all-reduce of a BatchNorm backward's [3][C] sums -> their MEAN over ranks.  The mean serves both
+    consumers without another launch: dz uses mean * (1 / local count) = global sums / global count, and d gamma / d beta
+    leave as (global sum) / world on every rank, which is what the reference's DDP mean of the per-rank LOCAL sums
+    (torch SyncBatchNorm returns local grad_weight / grad_bias, trainer.py:215-222) comes to."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(sums, op=dist.ReduceOp.AVG, group=group)
+    else:                                                                   # gloo (CPU-transport tests): no AVG
+        dist.all_reduce(sums, group=group)
+        sums.mul_(1.0 / sync_world(group))
+    _count(collectives=1)
+
+
+class _SyncBnAct(torch.autograd.Function):
+    """y = act(BN1(z1) [+ BN2(z2)]) [* mask[n]] [+ r1] [+ s * r2] with statistics of the GLOBAL batch.
+    forward : local statistics in wire format (one launch; none when `packed` comes from the previous BatchNorm's apply
+              launch; a tiny one when the producing GEMM left partial `sums`) -> all-gather -> combine + running statistics +
+              apply in one launch (`emit`: that launch also leaves the local statistics of y for the next BatchNorm);
+    backward: reduce -> all-reduce [3][C] -> apply (+ the gradient `z1` receives through its other use when `skip`)."""
+
+    @staticmethod
+    def forward(ctx, z1, g1, b1, rm1, rv1, z2, g2, b2, rm2, rv2, mask, r1, r2, r2_scale, act, eps, momentum, group, packed,
+                sums, skip, emit):
+        z1_in = z1
+        z1 = z1.contiguous()
+        N, C = z1.shape[0], z1.shape[1]
+        HW = z1.numel() // (N * C)
+        dt = z1.dtype
+        sfx = _suffix(z1)
+        dev = z1.device
+        z2 = None if z2 is None else z2.contiguous().to(dt)
+        r1 = None if r1 is None else r1.contiguous().to(dt)
+        r2 = None if r2 is None else r2.contiguous().to(dt)
+        g1f, b1f = g1.detach().float().contiguous(), b1.detach().float().contiguous()
+        g2f = None if g2 is None else g2.detach().float().contiguous()
+        b2f = None if b2 is None else b2.detach().float().contiguous()
+        maskf = None if mask is None else mask.detach().reshape(-1).float().contiguous()
+        two = z2 is not None
+        pitch = (4 if two else 2) * C + 1
+        if packed is None:
+            packed = torch.empty(pitch, device=dev, dtype=_F32)
+            if sums is not None and isinstance(sums, tuple) == two:
+                # producer-epilogue partial sums [C][P][2]; a pair fills the two halves of one row (the first call's count
+                # lands on mean2[0] and is overwritten by the second call, which runs after it on the stream)
+                for k, sk in enumerate(sums if two else (sums,)):
+                    call("ppea_bn_sync_stats_from_sums_f32", ptr(sk.contiguous(), _F32), sk.shape[1], C, N * HW,
+                         _ct.c_void_p(packed.data_ptr() + 8 * C * k), stream_ptr())
+                _count(launches=2 if two else 1)
+            else:
+                nws = _abi.lib.ppea_bn_sync_stats_workspace_bytes(N, C, HW, int(two)) // 4
+                ws = torch.empty(nws, device=dev, dtype=_F32) if nws else None
+                call(f"ppea_bn_sync_stats_{sfx}", ptr(z1), ptr(z2), ptr(packed), ptr(ws), N, C, HW, stream_ptr())
+                _count(launches=1 if not nws else (3 if two else 2))
+        assert packed.numel() == pitch
+        gathered = gather_rows(packed, group)
+        world = gathered.shape[0]
+        st = torch.empty(4, C, device=dev, dtype=_F32)          # mean1 | invstd1 | mean2 | invstd2
+        y = torch.empty_like(z1)
+        pn = torch.empty(2 * C + 1, device=dev, dtype=_F32) if emit else None
+        call(f"ppea_bn_sync_apply_{sfx}", ptr(z1), ptr(z2), ptr(gathered), world, _ptr_array((g1f, b1f, g2f, b2f)),
+             _ptr_array((rm1, rv1, rm2, rv2, st[0], st[1], st[2], st[3])), float(eps), float(momentum), ptr(maskf), ptr(r1),
+             ptr(r2), float(r2_scale), ptr(y), ptr(pn), int(act), N, C, HW, stream_ptr())
+        _count(launches=1)
+        ctx.save_for_backward(z1, z2, st, g1f, b1f, g2f, b2f, maskf)
+        ctx.act, ctx.r2_scale, ctx.group = int(act), float(r2_scale), group
+        ctx.has = (r1 is not None, r2 is not None)
+        ctx.pdt = (g1.dtype, b1.dtype, None if g2 is None else g2.dtype)
+        ctx.skip = bool(skip)
+        ctx.set_materialize_grads(False)
+        outs = [y, st]
+        ctx.mark_non_differentiable(st)
+        if skip:
+            outs.append(z1_in)
+        if emit:
+            outs.append(pn)
+            ctx.mark_non_differentiable(pn)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dy, _dst, *rest):
+        z1, z2, st, g1f, b1f, g2f, b2f, maskf = ctx.saved_tensors
+        N, C = z1.shape[0], z1.shape[1]
+        HW = z1.numel() // (N * C)
+        sfx = _suffix(z1)
+        dev = z1.device
+        if dy is None:
+            dy = torch.zeros_like(z1)
+        dy = dy.contiguous().to(z1.dtype)
+        dskip = rest[0] if (ctx.skip and rest and rest[0] is not None) else None
+        if dskip is not None:
+            dskip = dskip.contiguous().to(z1.dtype)
+        two = z2 is not None
+        stats = _stats_array((st[0], st[1], g1f, b1f, st[2] if two else None, st[3] if two else None, g2f, b2f))
+        sums = torch.empty(3, C, device=dev, dtype=_F32)
+        err = getattr(_abi.lib, f"ppea_bn_bwd_reduce_final_{sfx}")(
+            ptr(dy), ptr(z1), ptr(z2), stats, ptr(maskf), ptr(sums), ctx.act, N, C, HW, stream_ptr())
+        if err == -1:                       # large planes: per-plane partials + finalize
+            partial = torch.empty(C * N * 3, device=dev, dtype=_F32)
+            call(f"ppea_bn_bwd_reduce_{sfx}", ptr(dy), ptr(z1), ptr(z2), stats, ptr(maskf), ptr(partial), ctx.act, N, C,
+                 HW, stream_ptr())
+            call("ppea_bn_bwd_finalize_f32", ptr(partial), N, C, ptr(sums), stream_ptr())
+            _count(launches=2)
+        else:
+            _abi.check(err, "ppea_bn_bwd_reduce_final")
+            _count(launches=1)
+        reduce_sums(sums, ctx.group)
+        dz1 = torch.empty_like(z1)
+        dz2 = torch.empty_like(z2) if two else None
+        # sums now hold the mean over ranks: mean / local count == global sums / global count
+        call(f"ppea_bn_bwd_apply_acc_{sfx}", ptr(dy), ptr(z1), ptr(z2), stats, ptr(maskf), ptr(sums), 1.0 / float(N * HW),
+             ptr(dskip), ptr(dz1), ptr(dz2), ctx.act, N, C, HW, stream_ptr())
+        _count(launches=1)
+        n = ctx.needs_input_grad
+        dg1 = sums[1].to(ctx.pdt[0]) if n[1] else None
+        db1 = sums[0].to(ctx.pdt[1]) if n[2] else None
+        dg2 = sums[2].to(ctx.pdt[2]) if (two and n[6]) else None
+        db2 = sums[0].to(ctx.pdt[2]) if (two and n[7]) else None
+        dr1 = dy if ctx.has[0] else None
+        dr2 = (dy if ctx.r2_scale == 1.0 else dy * ctx.r2_scale) if ctx.has[1] else None
+        return (dz1, dg1, db1, None, None, dz2, dg2, db2, None, None, None, dr1, dr2) + (None,) * 9
+
+
+def sync_bn_act(z1, bn1, z2=None, bn2=None, mask=None, r1=None, r2=None, r2_scale=1.0, act=ACT_NONE, group=None,
+                packed=None, sums=None, skip=False, emit=False):
+    """-> (y, stats [4,C] = mean1 | invstd1 | mean2 | invstd2 of the global batch [, z1 for the residual use when `skip`]
+    [, local statistics of y in wire format when `emit`]).  Updates the running statistics of bn1 / bn2."""
+    return _SyncBnAct.apply(z1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, z2,
+                            None if bn2 is None else bn2.weight, None if bn2 is None else bn2.bias,
+                            None if bn2 is None else bn2.running_mean, None if bn2 is None else bn2.running_var,
+                            mask, r1, r2, r2_scale, act, bn1.eps, bn1.momentum, group, packed, sums, skip, emit)
 
 
 def bn_act_apply(z1, g1, b1, mean1, invstd1, z2=None, g2=None, b2=None, mean2=None, invstd2=None, mask=None,
@@ -1123,8 +1292,11 @@ def bf16_autocast():
 def conv_module(conv, x, act="none", reflect=False, out_nchw=False):
     """nn.Conv2d `conv` applied through the implicit-GEMM kernels when the bf16 step is running (x bf16, or an fp32
     image under bf16 autocast for the image-fed layers); None when this call is not served (caller uses the library)."""
-    if not (CONV_MFMA and x.is_cuda and conv.groups == 1 and conv.dilation[0] == 1 and conv.stride[0] in (1, 2)
-            and conv.kernel_size[0] == conv.kernel_size[1] and conv.kernel_size[0] <= 7):
+    if not (CONV_MFMA and x.is_cuda and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
+            and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2)
+            and conv.kernel_size[0] == conv.kernel_size[1] and conv.kernel_size[0] in (1, 3, 7)       # kernels built
+            and not isinstance(conv.padding, str) and conv.padding[0] == conv.padding[1]
+            and getattr(conv, "padding_mode", "zeros") == "zeros"):
         return None
     if x.dtype == _F32 and x.shape[1] < 8 and bf16_autocast():
         x = image_to_nhwc(x, 8)

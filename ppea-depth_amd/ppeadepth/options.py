@@ -34,6 +34,8 @@ class MonodepthOptions:
         a("--g_ffn", type=float, default=1.0)
         a("--dec_id", type=int, default=1)
         a("--dec_ratio", type=float, default=0.25)
+        a("--pred_depth_scale_factor", type=float, default=1.0)
+        a("--disable_median_scaling", action="store_true")
         for flag in ("adapter", "use_checkpoint", "dc", "notadabins", "freeze_teacher_and_pose", "freeze_pose",
                      "no_ssim", "disable_automasking", "disable_motion_masking", "no_matching_augmentation",
                      "v1_multiscale", "use_future_frame", "train_cs", "ddad", "fullft_reb", "dec_only", "lps2",

@@ -169,7 +169,7 @@ class Trainer:
                 pred_mono = pred_mono[:, 0]
         return pred[:, 0], pred_mono
 
-    def val(self, batches, gt_depths, eval_split="eigen", hard_test_mono=False, median_scaling=True):
+    def val(self, batches, gt_depths, eval_split="eigen", hard_test_mono=False, median_scaling=None):
         """`Trainer.val` (trainer.py:653-857) over an iterable of row-P batches and the split's ground-truth depth
         maps (`gt_depths.npz["data"]`, trainer.py:766-767): mean of (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3) for
         the multi-frame network and, unless the teacher is frozen, for the teacher."""
@@ -189,7 +189,12 @@ class Trainer:
         finally:
             model.train(was_training)
         disps = np.concatenate(disps)
-        mean_errors = evaluate.evaluate_disps(disps, gt_depths, eval_split, median_scaling)
+        # trainer.py:818-822: `--pred_depth_scale_factor`, `--disable_median_scaling` (the teacher is always median-scaled
+        # and never takes the scale factor, trainer.py:838-842)
+        scale = float(getattr(self.opt, "pred_depth_scale_factor", 1.0))
+        if median_scaling is None:
+            median_scaling = not getattr(self.opt, "disable_median_scaling", False)
+        mean_errors = evaluate.evaluate_disps(disps, gt_depths, eval_split, median_scaling, scale)
         if mono_flag:
             return mean_errors, evaluate.evaluate_disps(np.concatenate(disps_mono), gt_depths, eval_split, True)
         return mean_errors

