@@ -235,15 +235,6 @@ int ppea_bn_bwd_apply_f32(const void* dy, const void* z1, const void* z2, const 
 int ppea_bn_bwd_apply_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
                            const float* mask, const float* sums, float inv_count, void* dz1, void* dz2,
                            int act, int N, int C, int HW, void* stream);
-/* ... with `acc` (shape of z1, or NULL): dz1 = round(dz1) + acc, the gradient reaching z1 through its other consumer (the
- * block's residual connection, rka.py:289, 326) -- what ppea_bn_bwd_channel_* does in the one-launch form.  HW % 8 == 0. */
-int ppea_bn_bwd_apply_acc_f32(const void* dy, const void* z1, const void* z2, const float* const* stats,
-                              const float* mask, const float* sums, float inv_count, const void* acc, void* dz1, void* dz2,
-                              int act, int N, int C, int HW, void* stream);
-int ppea_bn_bwd_apply_acc_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
-                               const float* mask, const float* sums, float inv_count, const void* acc, void* dz1, void* dz2,
-                               int act, int N, int C, int HW, void* stream);
-
 /* ------------------------------------------------------------------------------------------
  * A2 across ranks  SyncBatchNorm on the fused kernels (csrc/bn_sync.hip).  Both encoders are nn.SyncBatchNorm in the
  *   reference (replknet_adapter.py:170-180; DDP step trainer.py:215-222): statistics of the GLOBAL batch.  One BatchNorm
@@ -257,8 +248,11 @@ int ppea_bn_bwd_apply_acc_bf16(const void* dy, const void* z1, const void* z2, c
  *         y in wire format (pitch 2C+1) -- the next BatchNorm over y (replknet_adapter.py:281, 312) then needs no
  *         statistics launch.  HW % 8 == 0, else PPEA_ERR_UNSUPPORTED (ppea_bn_sync_combine_f32 + ppea_bn_apply_*).
  *   prm / out as ppea_bn_fwd_channel_*.  ws: ppea_bn_sync_stats_workspace_bytes(N, C, HW, z2 != NULL) bytes (0 when one
- *   workgroup covers a channel).  Backward: ppea_bn_bwd_reduce(_final)_* -> all-reduce of sums [3][C] ->
- *   ppea_bn_bwd_apply_acc_* with inv_count = 1 / (global count).
+ *   workgroup covers a channel).  Backward: ppea_bn_bwd_reduce(_final)_* -> all-reduce (sum) of sums [3][C] ->
+ *   ppea_bn_sync_bwd_apply_* with inv_count = 1 / (global count); acc (shape of z1, or NULL): dz1 = round(dz1) + acc, the
+ *   gradient reaching z1 through its other consumer (the block's residual connection, rka.py:289, 326); dgb [3][C] (or
+ *   NULL) = sums * gscale: d beta | d gamma1 | d gamma2 with gscale = 1 / world -- the reference's DDP averages the
+ *   per-rank LOCAL sums torch's SyncBatchNorm returns (trainer.py:215-222), which is (global sum) / world.
  * ---------------------------------------------------------------------------------------- */
 long ppea_bn_sync_stats_workspace_bytes(int N, int C, int HW, int two);
 int ppea_bn_sync_stats_f32(const void* z1, const void* z2, float* packed, float* ws, int N, int C, int HW, void* stream);
@@ -270,6 +264,12 @@ int ppea_bn_sync_apply_f32(const void* z1, const void* z2, const float* gathered
 int ppea_bn_sync_apply_bf16(const void* z1, const void* z2, const float* gathered, int world, const float* const* prm,
                             float* const* out, float eps, float momentum, const float* mask, const void* r1, const void* r2,
                             float r2_scale, void* y, float* packed_next, int act, int N, int C, int HW, void* stream);
+int ppea_bn_sync_bwd_apply_f32(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                               const float* mask, const float* sums, float inv_count, const void* acc, void* dz1, void* dz2,
+                               float* dgb, float gscale, int act, int N, int C, int HW, void* stream);
+int ppea_bn_sync_bwd_apply_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                                const float* mask, const float* sums, float inv_count, const void* acc, void* dz1, void* dz2,
+                                float* dgb, float gscale, int act, int N, int C, int HW, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * A12 glue  nn.ReflectionPad2d(1) of the decoder's Conv3x3 (layers.py:119-135).  in [planes,H,W] ->

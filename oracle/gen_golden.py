@@ -248,8 +248,10 @@ DC_GRAD_KEYS = [k for k in GRAD_KEYS if not k.startswith(("depth.", "mono_depth.
     "mono_depth.deconv_adpt.weight"]
 
 
-def gen_e2e(name, B, H, W, extra=(), stride=1, seed=1, grad_keys=None, intrinsics="kitti"):
-    """Unmodified Trainer.process_batch + backward of the reference (config-1 style)."""
+def gen_e2e(name, B, H, W, extra=(), stride=1, seed=1, grad_keys=None, intrinsics="kitti", conditioned=False):
+    """Unmodified Trainer.process_batch + backward of the reference (config-1 style).
+    conditioned: rendered frames (synth.make_rendered_inputs) + the well-conditioned weight variant
+    (synth.synth_tensor(..., conditioned=True)) -- the fixture the bf16 step is pinned on."""
     opt = rh.parse_options(["--height", str(H), "--width", str(W), "--batch_size", str(B)]
                            + list(extra))
     torch.manual_seed(0)
@@ -260,9 +262,10 @@ def gen_e2e(name, B, H, W, extra=(), stride=1, seed=1, grad_keys=None, intrinsic
     if opt.dc:
         model.dc_ft_init()                 # Trainer.__init__, trainer.py:158-161 (Stage-2: decoder adapter only)
     model.train()
-    synth.fill_state_dict(model)
+    synth.fill_state_dict(model, conditioned=conditioned)
     tr = rh.build_reference_trainer(opt, model)
-    inputs = synth.make_inputs(B, H, W, intrinsics=intrinsics)
+    inputs = (synth.make_rendered_inputs(B, H, W, intrinsics=intrinsics) if conditioned
+              else synth.make_inputs(B, H, W, intrinsics=intrinsics))
     torch.manual_seed(seed)
     random.seed(seed)
     outputs, losses = tr.process_batch(inputs, True)
@@ -369,6 +372,10 @@ GENERATORS = {
     # Cityscapes size 192x512 (trainer.py:90-93) with Cityscapes-like intrinsics
     "e2e_dc": lambda: gen_e2e("e2e_dc", 2, 192, 512, extra=["--dc"], stride=8, grad_keys=DC_GRAD_KEYS,
                               intrinsics="cityscapes"),
+    # the WELL-CONDITIONED fixture: frames rendered from a known depth map + ego-motion, near-identity
+    # trunk, predicted pose = rendered pose; config 1/2's model at full size.  The bf16 step is held to absolute bounds
+    # on it (tests/test_e2e_gpu.py::test_engine_step_bf16_on_the_rendered_fixture)
+    "e2e_render": lambda: gen_e2e("e2e_render", 2, 192, 640, stride=8, conditioned=True),
 }
 
 

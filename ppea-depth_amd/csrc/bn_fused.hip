@@ -858,7 +858,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_flat(const T* __restrict__ d
                                                          const float* __restrict__ mask,
                                                          const float* __restrict__ sums, float inv_count,
                                                          const T* __restrict__ acc, T* __restrict__ dz1,
-                                                         T* __restrict__ dz2, int act, int C, int HW, long total8) {
+                                                         T* __restrict__ dz2, float* __restrict__ dgb, float gscale,
+                                                         int act, int C, int HW, long total8) {
     const long t = (long)blockIdx.x * TPB + threadIdx.x;
     if (t >= total8) return;
     const long i = t * V;
@@ -878,6 +879,9 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_flat(const T* __restrict__ d
     if (z2 != nullptr) { is2 = b2.invstd[c]; mu2 = b2.mean[c]; a2 = b2.gamma[c] * is2; o2 = b2.beta[c] - mu2 * a2; }
     const float m = (mask != nullptr) ? mask[n] : 1.f;
     const float mg = sums[c] * inv_count, m1 = sums[C + c] * inv_count, m2 = sums[2 * C + c] * inv_count;
+    if (dgb != nullptr && n == 0 && i == plane * HW) {      // the thread at the head of plane (0, c): one writer per channel
+        dgb[c] = sums[c] * gscale; dgb[C + c] = sums[C + c] * gscale; dgb[2 * C + c] = sums[2 * C + c] * gscale;
+    }
     float x1[V], x2[V], d[V], o1v[V], o2v[V];
     ld8<T>(z1 + i, x1);
     if (z2 != nullptr) ld8<T>(z2 + i, x2);
@@ -961,17 +965,17 @@ int bwd_reduce_impl(const void* dy, const void* z1, const void* z2, const float*
 template <typename T>
 int bwd_apply_impl(const void* dy, const void* z1, const void* z2, const float* const* st, const float* mask,
                    const float* sums, float inv_count, void* dz1, void* dz2, int act, int N, int C, int HW,
-                   void* stream, const void* acc = nullptr) {
+                   void* stream, const void* acc = nullptr, float* dgb = nullptr, float gscale = 1.f) {
     if (N <= 0 || C <= 0 || HW <= 0 || act < 0 || act > 2) return PPEA_ERR_UNSUPPORTED;
     const Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
     if (HW % V == 0) {
         const long total8 = (long)N * C * HW / V;
         hipLaunchKernelGGL(bn_bwd_apply_flat<T>, dim3((unsigned)((total8 + TPB - 1) / TPB)), dim3(TPB), 0,
                            (hipStream_t)stream, (const T*)dy, (const T*)z1, (const T*)z2, b1, b2, mask, sums,
-                           inv_count, (const T*)acc, (T*)dz1, (T*)dz2, act, C, HW, total8);
+                           inv_count, (const T*)acc, (T*)dz1, (T*)dz2, dgb, gscale, act, C, HW, total8);
         return launch_status();
     }
-    if (acc != nullptr) return PPEA_ERR_UNSUPPORTED;
+    if (acc != nullptr || dgb != nullptr) return PPEA_ERR_UNSUPPORTED;
     const int chunks = plane_chunks((long)N * C, HW);
     hipLaunchKernelGGL(bn_bwd_apply<T>, dim3((unsigned)((long)N * C * chunks)), dim3(TPB), 0, (hipStream_t)stream,
                        (const T*)dy, (const T*)z1, (const T*)z2, b1, b2, mask, sums, inv_count, (T*)dz1, (T*)dz2, act,
@@ -1201,17 +1205,19 @@ int ppea_bn_bwd_apply_bf16(const void* dy, const void* z1, const void* z2, const
                            int N, int C, int HW, void* stream) {
     return bwd_apply_impl<uint16_t>(dy, z1, z2, stats, mask, sums, inv_count, dz1, dz2, act, N, C, HW, stream);
 }
-// ... with `acc` (same shape as z1, or NULL): dz1 = round(dz1) + acc, the gradient that reaches z1 through its other consumer
-// (a block's residual connection) -- what ppea_bn_bwd_channel_* does in the one-launch form.  HW % 8 == 0.
-int ppea_bn_bwd_apply_acc_f32(const void* dy, const void* z1, const void* z2, const float* const* stats,
-                              const float* mask, const float* sums, float inv_count, const void* acc, void* dz1, void* dz2,
-                              int act, int N, int C, int HW, void* stream) {
-    return bwd_apply_impl<float>(dy, z1, z2, stats, mask, sums, inv_count, dz1, dz2, act, N, C, HW, stream, acc);
-}
-int ppea_bn_bwd_apply_acc_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
+// SyncBN backward apply (bn_sync.hip's counterpart): `sums` are the all-reduced sums of the GLOBAL batch, inv_count =
+// 1 / (global count); acc (shape of z1, or NULL): dz1 = round(dz1) + acc, the gradient reaching z1 through its other consumer
+// (what ppea_bn_bwd_channel_* does in the one-launch form); dgb [3][C] (or NULL) = sums * gscale, the parameter gradients
+// d beta | d gamma1 | d gamma2 scaled for the data-parallel mean (gscale = 1 / world).  HW % 8 == 0.
+int ppea_bn_sync_bwd_apply_f32(const void* dy, const void* z1, const void* z2, const float* const* stats,
                                const float* mask, const float* sums, float inv_count, const void* acc, void* dz1, void* dz2,
-                               int act, int N, int C, int HW, void* stream) {
-    return bwd_apply_impl<uint16_t>(dy, z1, z2, stats, mask, sums, inv_count, dz1, dz2, act, N, C, HW, stream, acc);
+                               float* dgb, float gscale, int act, int N, int C, int HW, void* stream) {
+    return bwd_apply_impl<float>(dy, z1, z2, stats, mask, sums, inv_count, dz1, dz2, act, N, C, HW, stream, acc, dgb, gscale);
+}
+int ppea_bn_sync_bwd_apply_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
+                                const float* mask, const float* sums, float inv_count, const void* acc, void* dz1, void* dz2,
+                                float* dgb, float gscale, int act, int N, int C, int HW, void* stream) {
+    return bwd_apply_impl<uint16_t>(dy, z1, z2, stats, mask, sums, inv_count, dz1, dz2, act, N, C, HW, stream, acc, dgb, gscale);
 }
 
 }  // extern "C"

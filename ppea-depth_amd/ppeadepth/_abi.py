@@ -83,8 +83,8 @@ SIGNATURES = {
     "ppea_bn_bwd_finalize_f32": [_vp, _i, _i, _vp, _vp],
     "ppea_bn_bwd_apply_f32": [_vp] * 6 + [_f, _vp, _vp] + [_i] * 4 + [_vp],
     "ppea_bn_bwd_apply_bf16": [_vp] * 6 + [_f, _vp, _vp] + [_i] * 4 + [_vp],
-    "ppea_bn_bwd_apply_acc_f32": [_vp] * 6 + [_f, _vp, _vp, _vp] + [_i] * 4 + [_vp],
-    "ppea_bn_bwd_apply_acc_bf16": [_vp] * 6 + [_f, _vp, _vp, _vp] + [_i] * 4 + [_vp],
+    "ppea_bn_sync_bwd_apply_f32": [_vp] * 6 + [_f, _vp, _vp, _vp, _vp, _f] + [_i] * 4 + [_vp],
+    "ppea_bn_sync_bwd_apply_bf16": [_vp] * 6 + [_f, _vp, _vp, _vp, _vp, _f] + [_i] * 4 + [_vp],
     "ppea_bn_sync_stats_workspace_bytes": [_i] * 4,
     "ppea_bn_sync_stats_f32": [_vp] * 4 + [_i] * 3 + [_vp],
     "ppea_bn_sync_stats_bf16": [_vp] * 4 + [_i] * 3 + [_vp],

@@ -137,10 +137,8 @@ def _global_stats(bn, z, sums=None):
     world = dist.get_world_size(group)
     packed = ops.bn_local_stats_packed(z)
     gathered = torch.empty(world, packed.numel(), device=z.device, dtype=packed.dtype)
-    if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(gathered, packed, group=group)
-    else:
-        dist.all_gather(list(gathered.unbind(0)), packed, group=group)     # gloo has no tensor form
+    gathered[dist.get_rank(group)].copy_(packed)
+    ops.gather_rows(gathered, group)
     mean, invstd = ops.bn_sync_combine(gathered, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
     return mean, invstd, float(cnt * world), (group,)
 
@@ -162,10 +160,8 @@ def _global_stats_pair(bn1, z1, bn2, z2, sums=None):
     n1 = p1.numel()
     packed = torch.cat([p1, p2])
     gathered = torch.empty(world, packed.numel(), device=z1.device, dtype=packed.dtype)
-    if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(gathered, packed, group=group)
-    else:
-        dist.all_gather(list(gathered.unbind(0)), packed, group=group)
+    gathered[dist.get_rank(group)].copy_(packed)
+    ops.gather_rows(gathered, group)
     out = []
     for bn, z, g in ((bn1, z1, gathered[:, :n1]), (bn2, z2, gathered[:, n1:])):
         mean, invstd = ops.bn_sync_combine(g.contiguous(), bn.eps, bn.momentum, bn.running_mean, bn.running_var)
@@ -292,10 +288,10 @@ def fused_bn_act_next(z, bnA, bnB, mask=None, r1=None, r2=None, r2_scale=1.0):
         # several ranks: stats(z) -> gather -> [apply A + local statistics of y] -> gather -> apply B: the second
         # BatchNorm needs no statistics launch, and its backward adds the residual use's gradient of y in its apply launch
         group = getattr(bnA, "group", None)
-        y, stA, pk = ops.sync_bn_act(z, bnA, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, group=group, emit=True)
+        y, stA, tab = ops.sync_bn_act(z, bnA, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, group=group, emit=True)
         _book_sync([(z, bnA)], stA, z)
         want_skip = bool(torch.is_grad_enabled() and y.requires_grad)
-        outs = ops.sync_bn_act(y, bnB, group=group, packed=pk, skip=want_skip)
+        outs = ops.sync_bn_act(y, bnB, group=group, table=tab, skip=want_skip)
         _book_sync([(y, bnB)], outs[1], y)
         return (outs[2] if want_skip else y), outs[0]
     if not (BN_CHAIN and ops.bn_channel_ok(z) and bnA.training and bnB.training

@@ -499,13 +499,16 @@ class _BnAct(torch.autograd.Function):
         elif err != 0:
             _abi.check(err, "ppea_bn_bwd_reduce_final")
         inv_count = 1.0 / ctx.count
-        if ctx.group is not None:                      # SyncBN: mean of the sums over ranks (ctx.count is the global count)
+        gscale = None
+        if ctx.group is not None:                      # SyncBN: sums of the global batch (ctx.count is the global count)
             reduce_sums(sums, ctx.group[0])
-            inv_count *= sync_world(ctx.group[0])
+            gscale = 1.0 / sync_world(ctx.group[0])    # d gamma / d beta: see _SyncBnAct
         dz1 = torch.empty_like(z1)
         dz2 = None if z2 is None else torch.empty_like(z2)
         call(f"ppea_bn_bwd_apply_{sfx}", ptr(dy), ptr(z1), ptr(z2), st, ptr(maskf), ptr(sums), inv_count,
              ptr(dz1), ptr(dz2), ctx.act, N, C, HW, stream_ptr())
+        if gscale is not None:
+            sums = sums * gscale
         dg1 = sums[1].to(ctx.pdt[0]) if ctx.needs_input_grad[1] else None
         db1 = sums[0].to(ctx.pdt[1]) if ctx.needs_input_grad[2] else None
         dg2 = sums[2].to(ctx.pdt[2]) if (z2 is not None and ctx.needs_input_grad[6]) else None
@@ -686,42 +689,42 @@ def sync_world(group):
     return dist.get_world_size(group)
 
 
-def gather_rows(packed, group):
-    """ONE all-gather of a rank's packed statistics -> [world, len(packed)]."""
+def sync_rank(group):
     import torch.distributed as dist
-    world = sync_world(group)
-    gathered = torch.empty(world, packed.numel(), device=packed.device, dtype=packed.dtype)
+    return dist.get_rank(group)
+
+
+def gather_rows(table, group):
+    """ONE all-gather, IN PLACE: `table` [world, pitch] arrives with this rank's row filled (the statistics kernel wrote
+    straight into it) and leaves with every rank's row -- no staging copy on either side of the collective."""
+    import torch.distributed as dist
+    mine = table[sync_rank(group)]
     if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(gathered, packed, group=group)
+        dist.all_gather_into_tensor(table, mine, group=group)
     else:
-        dist.all_gather(list(gathered.unbind(0)), packed, group=group)     # gloo has no tensor form
+        dist.all_gather(list(table.unbind(0)), mine.clone(), group=group)     # gloo has no tensor form
     _count(collectives=1)
-    return gathered
 
 
 def reduce_sums(sums, group):
-    """ONE in-place all-reduce of a BatchNorm backward's [3][C] sums -> their MEAN over ranks.  The mean serves both
-    consumers without another launch: dz uses mean * (1 / local count) = global sums / global count, and d gamma / d beta
-    leave as (global sum) / world on every rank, which is what the reference's DDP mean of the per-rank LOCAL sums
-    (torch SyncBatchNorm returns local grad_weight / grad_bias, trainer.py:215-222) comes to."""
+    """ONE in-place all-reduce (sum) of a BatchNorm backward's [3][C] sums."""
     import torch.distributed as dist
-    if dist.get_backend(group) == "nccl":
-        dist.all_reduce(sums, op=dist.ReduceOp.AVG, group=group)
-    else:                                                                   # gloo (CPU-transport tests): no AVG
-        dist.all_reduce(sums, group=group)
-        sums.mul_(1.0 / sync_world(group))
+    dist.all_reduce(sums, group=group)
     _count(collectives=1)
 
 
 class _SyncBnAct(torch.autograd.Function):
     """y = act(BN1(z1) [+ BN2(z2)]) [* mask[n]] [+ r1] [+ s * r2] with statistics of the GLOBAL batch.
-    forward : local statistics in wire format (one launch; none when `packed` comes from the previous BatchNorm's apply
-              launch; a tiny one when the producing GEMM left partial `sums`) -> all-gather -> combine + running statistics +
-              apply in one launch (`emit`: that launch also leaves the local statistics of y for the next BatchNorm);
-    backward: reduce -> all-reduce [3][C] -> apply (+ the gradient `z1` receives through its other use when `skip`)."""
+    forward : local statistics in wire format written into this rank's row of the gather table (one launch; none when
+              `table` comes from the previous BatchNorm's apply launch; a tiny one when the producing GEMM left partial
+              `sums`) -> in-place all-gather -> combine + running statistics + apply in one launch (`emit`: that launch
+              also leaves the local statistics of y in the next BatchNorm's table);
+    backward: reduce -> all-reduce [3][C] -> apply (+ the gradient `z1` receives through its other use when `skip`).
+              d gamma / d beta leave as (global sum) / world: what the reference's DDP mean of the per-rank LOCAL sums
+              comes to (torch's SyncBatchNorm returns local grad_weight / grad_bias; trainer.py:215-222)."""
 
     @staticmethod
-    def forward(ctx, z1, g1, b1, rm1, rv1, z2, g2, b2, rm2, rv2, mask, r1, r2, r2_scale, act, eps, momentum, group, packed,
+    def forward(ctx, z1, g1, b1, rm1, rv1, z2, g2, b2, rm2, rv2, mask, r1, r2, r2_scale, act, eps, momentum, group, table,
                 sums, skip, emit):
         z1_in = z1
         z1 = z1.contiguous()
@@ -739,32 +742,34 @@ class _SyncBnAct(torch.autograd.Function):
         maskf = None if mask is None else mask.detach().reshape(-1).float().contiguous()
         two = z2 is not None
         pitch = (4 if two else 2) * C + 1
-        if packed is None:
-            packed = torch.empty(pitch, device=dev, dtype=_F32)
+        world, rank = sync_world(group), sync_rank(group)
+        if table is None:
+            table = torch.empty(world, pitch, device=dev, dtype=_F32)
+            row = _ct.c_void_p(table.data_ptr() + 4 * pitch * rank)
             if sums is not None and isinstance(sums, tuple) == two:
                 # producer-epilogue partial sums [C][P][2]; a pair fills the two halves of one row (the first call's count
                 # lands on mean2[0] and is overwritten by the second call, which runs after it on the stream)
                 for k, sk in enumerate(sums if two else (sums,)):
                     call("ppea_bn_sync_stats_from_sums_f32", ptr(sk.contiguous(), _F32), sk.shape[1], C, N * HW,
-                         _ct.c_void_p(packed.data_ptr() + 8 * C * k), stream_ptr())
+                         _ct.c_void_p(row.value + 8 * C * k), stream_ptr())
                 _count(launches=2 if two else 1)
             else:
                 nws = _abi.lib.ppea_bn_sync_stats_workspace_bytes(N, C, HW, int(two)) // 4
                 ws = torch.empty(nws, device=dev, dtype=_F32) if nws else None
-                call(f"ppea_bn_sync_stats_{sfx}", ptr(z1), ptr(z2), ptr(packed), ptr(ws), N, C, HW, stream_ptr())
+                call(f"ppea_bn_sync_stats_{sfx}", ptr(z1), ptr(z2), row, ptr(ws), N, C, HW, stream_ptr())
                 _count(launches=1 if not nws else (3 if two else 2))
-        assert packed.numel() == pitch
-        gathered = gather_rows(packed, group)
-        world = gathered.shape[0]
+        assert tuple(table.shape) == (world, pitch)
+        gather_rows(table, group)
         st = torch.empty(4, C, device=dev, dtype=_F32)          # mean1 | invstd1 | mean2 | invstd2
         y = torch.empty_like(z1)
-        pn = torch.empty(2 * C + 1, device=dev, dtype=_F32) if emit else None
-        call(f"ppea_bn_sync_apply_{sfx}", ptr(z1), ptr(z2), ptr(gathered), world, _ptr_array((g1f, b1f, g2f, b2f)),
+        nxt = torch.empty(world, 2 * C + 1, device=dev, dtype=_F32) if emit else None
+        call(f"ppea_bn_sync_apply_{sfx}", ptr(z1), ptr(z2), ptr(table), world, _ptr_array((g1f, b1f, g2f, b2f)),
              _ptr_array((rm1, rv1, rm2, rv2, st[0], st[1], st[2], st[3])), float(eps), float(momentum), ptr(maskf), ptr(r1),
-             ptr(r2), float(r2_scale), ptr(y), ptr(pn), int(act), N, C, HW, stream_ptr())
+             ptr(r2), float(r2_scale), ptr(y), None if nxt is None else _ct.c_void_p(nxt.data_ptr() + 4 * (2 * C + 1) * rank),
+             int(act), N, C, HW, stream_ptr())
         _count(launches=1)
         ctx.save_for_backward(z1, z2, st, g1f, b1f, g2f, b2f, maskf)
-        ctx.act, ctx.r2_scale, ctx.group = int(act), float(r2_scale), group
+        ctx.act, ctx.r2_scale, ctx.group, ctx.world = int(act), float(r2_scale), group, world
         ctx.has = (r1 is not None, r2 is not None)
         ctx.pdt = (g1.dtype, b1.dtype, None if g2 is None else g2.dtype)
         ctx.skip = bool(skip)
@@ -774,8 +779,8 @@ class _SyncBnAct(torch.autograd.Function):
         if skip:
             outs.append(z1_in)
         if emit:
-            outs.append(pn)
-            ctx.mark_non_differentiable(pn)
+            outs.append(nxt)
+            ctx.mark_non_differentiable(nxt)
         return tuple(outs)
 
     @staticmethod
@@ -805,31 +810,33 @@ class _SyncBnAct(torch.autograd.Function):
         else:
             _abi.check(err, "ppea_bn_bwd_reduce_final")
             _count(launches=1)
-        reduce_sums(sums, ctx.group)
+        reduce_sums(sums, ctx.group)                            # -> sums of the global batch
         dz1 = torch.empty_like(z1)
         dz2 = torch.empty_like(z2) if two else None
-        # sums now hold the mean over ranks: mean / local count == global sums / global count
-        call(f"ppea_bn_bwd_apply_acc_{sfx}", ptr(dy), ptr(z1), ptr(z2), stats, ptr(maskf), ptr(sums), 1.0 / float(N * HW),
-             ptr(dskip), ptr(dz1), ptr(dz2), ctx.act, N, C, HW, stream_ptr())
+        dgb = torch.empty(3, C, device=dev, dtype=_F32)         # d beta | d gamma1 | d gamma2, already divided by world
+        call(f"ppea_bn_sync_bwd_apply_{sfx}", ptr(dy), ptr(z1), ptr(z2), stats, ptr(maskf), ptr(sums),
+             1.0 / float(N * HW * ctx.world), ptr(dskip), ptr(dz1), ptr(dz2), ptr(dgb), 1.0 / ctx.world, ctx.act, N, C, HW,
+             stream_ptr())
         _count(launches=1)
         n = ctx.needs_input_grad
-        dg1 = sums[1].to(ctx.pdt[0]) if n[1] else None
-        db1 = sums[0].to(ctx.pdt[1]) if n[2] else None
-        dg2 = sums[2].to(ctx.pdt[2]) if (two and n[6]) else None
-        db2 = sums[0].to(ctx.pdt[2]) if (two and n[7]) else None
+        dg1 = dgb[1].to(ctx.pdt[0]) if n[1] else None
+        db1 = dgb[0].to(ctx.pdt[1]) if n[2] else None
+        dg2 = dgb[2].to(ctx.pdt[2]) if (two and n[6]) else None
+        db2 = dgb[0].to(ctx.pdt[2]) if (two and n[7]) else None
         dr1 = dy if ctx.has[0] else None
         dr2 = (dy if ctx.r2_scale == 1.0 else dy * ctx.r2_scale) if ctx.has[1] else None
         return (dz1, dg1, db1, None, None, dz2, dg2, db2, None, None, None, dr1, dr2) + (None,) * 9
 
 
 def sync_bn_act(z1, bn1, z2=None, bn2=None, mask=None, r1=None, r2=None, r2_scale=1.0, act=ACT_NONE, group=None,
-                packed=None, sums=None, skip=False, emit=False):
+                table=None, sums=None, skip=False, emit=False):
     """-> (y, stats [4,C] = mean1 | invstd1 | mean2 | invstd2 of the global batch [, z1 for the residual use when `skip`]
-    [, local statistics of y in wire format when `emit`]).  Updates the running statistics of bn1 / bn2."""
+    [, the next BatchNorm's gather table with this rank's statistics of y filled in when `emit`]).  `table`: such a table
+    from the launch that produced z1.  Updates the running statistics of bn1 / bn2."""
     return _SyncBnAct.apply(z1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, z2,
                             None if bn2 is None else bn2.weight, None if bn2 is None else bn2.bias,
                             None if bn2 is None else bn2.running_mean, None if bn2 is None else bn2.running_var,
-                            mask, r1, r2, r2_scale, act, bn1.eps, bn1.momentum, group, packed, sums, skip, emit)
+                            mask, r1, r2, r2_scale, act, bn1.eps, bn1.momentum, group, table, sums, skip, emit)
 
 
 def bn_act_apply(z1, g1, b1, mean1, invstd1, z2=None, g2=None, b2=None, mean2=None, invstd2=None, mask=None,

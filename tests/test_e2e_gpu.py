@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-def _build(device, B, H, W, use_checkpoint=False, amp=None, rep_size="b", dc=False):
+def _build(device, B, H, W, use_checkpoint=False, amp=None, rep_size="b", dc=False, conditioned=False):
     from ppeadepth import networks, options, rng
     from ppeadepth.trainer import Trainer
     opt = options.default_options(height=H, width=W, batch_size=B, use_checkpoint=use_checkpoint, rep_size=rep_size,
@@ -26,10 +26,15 @@ def _build(device, B, H, W, use_checkpoint=False, amp=None, rep_size="b", dc=Fal
     model = networks.RepDepth(opt)
     if dc:
         model.dc_ft_init()                       # reference Trainer.__init__, trainer.py:158-161
-    synth.fill_state_dict(model)
+    synth.fill_state_dict(model, conditioned=conditioned)
     model.to(device).train()
     rng.set_mode("reference")
     return opt, model, Trainer(opt, model, device, amp_dtype=amp)
+
+
+def _inputs(B, H, W, intrinsics="kitti", conditioned=False):
+    return (synth.make_rendered_inputs(B, H, W, intrinsics=intrinsics) if conditioned
+            else synth.make_inputs(B, H, W, intrinsics=intrinsics))
 
 
 def _key(k):
@@ -39,14 +44,14 @@ def _key(k):
 
 # how each golden was generated (oracle/gen_golden.py GENERATORS)
 CONFIG_OF = {"e2e_small_ckpt": dict(use_checkpoint=True), "e2e_l": dict(rep_size="l"),
-             "e2e_dc": dict(dc=True, intrinsics="cityscapes")}
+             "e2e_dc": dict(dc=True, intrinsics="cityscapes"), "e2e_render": dict(conditioned=True)}
 
 
-def _run(golden_name, golden, device, use_checkpoint=False, rep_size="b", dc=False, intrinsics="kitti"):
+def _run(golden_name, golden, device, use_checkpoint=False, rep_size="b", dc=False, intrinsics="kitti", conditioned=False):
     g = golden(golden_name)
     B, H, W, stride, seed = (int(v) for v in g["meta"])
-    opt, model, tr = _build(device, B, H, W, use_checkpoint, rep_size=rep_size, dc=dc)
-    inputs = {k: v.to(device) for k, v in synth.make_inputs(B, H, W, intrinsics=intrinsics).items()}
+    opt, model, tr = _build(device, B, H, W, use_checkpoint, rep_size=rep_size, dc=dc, conditioned=conditioned)
+    inputs = {k: v.to(device) for k, v in _inputs(B, H, W, intrinsics, conditioned).items()}
     torch.manual_seed(seed)
     random.seed(seed)
     outputs, losses = tr.process_batch(inputs, True)
@@ -55,7 +60,7 @@ def _run(golden_name, golden, device, use_checkpoint=False, rep_size="b", dc=Fal
 
 
 def _engine_step(golden_name, golden, device, bf16, graph, use_checkpoint=False, rep_size="b", dc=False,
-                 intrinsics="kitti"):
+                 intrinsics="kitti", conditioned=False):
     """ONE training step through `TrainEngine` -- the object bench.py times -- from the golden's initial state and with
     the reference's random draws: bf16 = autocast + bf16 working weights with fp32 masters (MFMA kernels), graph =
     the whole step replayed from a hipGraph (state restored after the capture's warm-up steps)."""
@@ -64,9 +69,9 @@ def _engine_step(golden_name, golden, device, bf16, graph, use_checkpoint=False,
     g = golden(golden_name)
     B, H, W, stride, seed = (int(v) for v in g["meta"])
     opt, model, tr = _build(device, B, H, W, use_checkpoint, amp=torch.bfloat16 if bf16 else None,
-                            rep_size=rep_size, dc=dc)
+                            rep_size=rep_size, dc=dc, conditioned=conditioned)
     eng = TrainEngine(tr, lr=1e-4, bf16_params=bf16)
-    inputs = {k: v.to(device) for k, v in synth.make_inputs(B, H, W, intrinsics=intrinsics).items()}
+    inputs = {k: v.to(device) for k, v in _inputs(B, H, W, intrinsics, conditioned).items()}
     try:
         if graph:
             eng.capture(inputs, warmup=1, restore_state=True)
@@ -200,6 +205,11 @@ def test_e2e_full_size_vs_reference_golden(device, golden):
     _check(*_run("e2e_full", golden, device))
 
 
+def test_e2e_rendered_well_conditioned_vs_reference_golden(device, golden):
+    """The well-conditioned fixture (rendered frames, near-identity trunk, predicted pose = rendered pose), fp32."""
+    _check(*_run("e2e_render", golden, device, conditioned=True))
+
+
 def test_e2e_replknet31l_vs_reference_golden(device, golden):
     """BASELINE config 4's model: RepLKNet-31L (C = 192/384/768/1536), fp32, reduced frame size."""
     _check(*_run("e2e_l", golden, device, rep_size="l"))
@@ -224,7 +234,7 @@ TOL_F32 = dict(loss=1e-3, out=1e-3, l2=1e-3, share=5e-3, exact=0.0, grad_abs=2e-
 # eager fp32 at the other sizes is what the direct-path tests above already run; the engine adds the flat optimizer
 # layout, the step stream and the graph, which one eager case covers
 @pytest.mark.parametrize("name,graph", [("e2e_small", False), ("e2e_small", True), ("e2e_full", True),
-                                        ("e2e_l", True), ("e2e_dc", True)])
+                                        ("e2e_l", True), ("e2e_dc", True), ("e2e_render", True)])
 def test_engine_step_fp32_vs_reference_golden(device, golden, name, graph):
     """TrainEngine.step -- the object bench.py times -- in fp32, eager and replayed from a hipGraph: losses, disp /
     depth / warps / poses, cost-volume argmin maps, 15 gradients (sum, head, 4096-element sample), BN running
@@ -287,6 +297,51 @@ def test_engine_step_bf16_vs_reference_golden_and_torch_bf16(device, golden, nam
             # a mask derived from the chaotic argmin): wider band than the tensor-valued L2 errors
             slack, floor = (2.5, 1e-2) if grp == "loss" else (1.5, 2 ** -8)
             if v > slack * torch_err[k] + floor:
+                bad[k] = (v, "torch bf16", torch_err[k])
+        assert not bad, (graph, bad)
+
+
+# Absolute bounds for the bf16 step on the WELL-CONDITIONED fixture (tests/golden/e2e_render.npz: frames rendered from a
+# known depth map + ego-motion, near-identity trunk, predicted pose = rendered pose; oracle/gen_golden.py).  Measured
+# (profiles/r03_bf16_render_parity.txt, eager == graph replay bit for bit): losses 6e-4, disp / depth L2 1.2e-2, warps
+# 1-2e-2, decoder / stage-2 adapter gradient cosines 0.995-0.99999.
+RENDER_ABS = {"loss:loss": 3e-3, "loss:loss/0": 3e-3, "loss:reproj_loss/0": 3e-3, "loss:consistency_loss/0": 3e-3,
+              "l2:disp|0": 2e-2, "l2:mono_disp|0": 2e-2, "l2:depth|0|0": 2e-2, "l2:mono_depth|0|0": 2e-2,
+              "l2:sample|-1|0": 3e-2, "l2:sample|1|0": 3e-2, "l2:cam_T_cam|0|-1": 1e-4, "l2:cam_T_cam|0|1": 1e-4,
+              "l2:translation|0|-1": 1.5e-2, "l2:translation|0|1": 1.5e-2, "out:relative_pose": 1e-2,
+              "bins_after": 1e-4, "exact:out:augmentation_mask": 0.0, "share:out:consistency_mask": 1e-3,
+              "buf:encoder.replk.stem.0.bn.running_mean": 5e-3, "buf:encoder.replk.stem.0.bn.running_var": 1e-3,
+              "buf:mono_encoder.stages.3.blocks.3.pw2.bn.running_var": 1e-2,
+              "buf:pose_encoder.encoder.bn1.running_mean": 5e-3}
+# 1 - cosine(gradient sample, fp32 golden): >= 0.99 where the problem is well conditioned ...
+RENDER_COS = {"depth.disp_convs.0.conv.weight": 1e-2, "depth.upconvs_0.0.conv.conv.weight": 1e-2,
+              "mono_depth.upconvs_1.4.conv.conv.weight": 2e-2,
+              "encoder.replk.stages.0.blocks.1.mlp_adapter.D_fc2.weight": 1e-2,
+              "encoder.replk.stages.2.blocks.10.adapter.D_fc2.weight": 1e-2,
+              # ... 0.96 for these two ...
+              "encoder.replk.stages.3.blocks.3.preffn_bn.weight": 4e-2,
+              "mono_encoder.stages.2.blocks.35.mlp_adapter.D_fc1.bias": 4e-2}
+# ... and for the rest (stem / stage 0 of both encoders, reduce_conv behind the argmin masks, the pose network) rounding
+# the dense weights and the frames to bf16 ALONE moves the fp32 oracle's own gradient to cosine 0.67-0.94 (CPU, the
+# exploration recorded in DESIGN.md 2): any bf16 execution lands there, so those keys are held to the band of torch's
+# own bf16 autocast of the same model.
+
+
+def test_engine_step_bf16_on_the_rendered_fixture(device, golden):
+    """The benchmarked arithmetic (bf16 autocast, bf16 working weights with fp32 masters, every MFMA kernel), eager and
+    replayed from a hipGraph, against the reference's fp32 golden on the well-conditioned fixture: ABSOLUTE bounds, no
+    comparator, for losses, disp / depth, warps, poses, running statistics and the well-conditioned gradients."""
+    cfg = CONFIG_OF["e2e_render"]
+    with _plain_torch_bf16():
+        torch_err = _errors(*_engine_step("e2e_render", golden, device, bf16=True, graph=False, **cfg))
+    for graph in (False, True):
+        errs = _errors(*_engine_step("e2e_render", golden, device, bf16=True, graph=graph, **cfg))
+        bad = {k: (errs[k], b) for k, b in RENDER_ABS.items() if errs[k] > b}
+        for name, b in RENDER_COS.items():
+            if errs["grad_cos:" + name] > b:
+                bad["grad_cos:" + name] = (errs["grad_cos:" + name], b)
+        for k, v in errs.items():
+            if k.startswith("grad_cos:") and k[9:] not in RENDER_COS and v > 1.5 * torch_err[k] + 2e-2:
                 bad[k] = (v, "torch bf16", torch_err[k])
         assert not bad, (graph, bad)
 
@@ -383,11 +438,13 @@ def test_graph_replay_equals_eager_steps_with_adaptive_bins(device, bf16):
     from ppeadepth.dist import TrainEngine
     B, H, W, N = 2, 64, 96, 4
     amp = torch.bfloat16 if bf16 else None
-    batches = [{k: v.to(device) for k, v in synth.make_inputs(B, H, W, seed=50 + i, smooth=True).items()}
+    # the well-conditioned variant (rendered frames, near-identity trunk): two executions with different summation orders
+    # then drift apart slowly instead of chaotically, so the comparison of later steps means something
+    batches = [{k: v.to(device) for k, v in synth.make_rendered_inputs(B, H, W, seed=50 + i).items()}
                for i in range(N)]
     runs = []
     for graph in (False, True):
-        opt, model, tr = _build(device, B, H, W, use_checkpoint=True, amp=amp)
+        opt, model, tr = _build(device, B, H, W, use_checkpoint=True, amp=amp, conditioned=True)
         # reference-order draws (DropPath masks, tie-break noise) in both runs: with near-identity poses the
         # automask is decided by the 1e-5 noise at many pixels, so the two runs must see the same stream
         rng.set_mode("reference")

@@ -153,18 +153,19 @@ def test_depth_bin_tracker(golden):
 
 
 # ---------------------------------------------------------------------------
-def _run_e2e(g, use_checkpoint=False, rep_size="b", dc=False, intrinsics="kitti"):
+def _run_e2e(g, use_checkpoint=False, rep_size="b", dc=False, intrinsics="kitti", conditioned=False):
     B, H, W, stride, seed = (int(v) for v in g["meta"])
     opt = types.SimpleNamespace(
         rep_size=rep_size, g_blk=1.0, g_ffn=1.0, use_checkpoint=use_checkpoint, height=H, width=W,
         batch_size=B, num_depth_bins=96, min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3, dc=dc)
     from oracle import model_spec
-    sd = {k: synth.synth_tensor(k, torch.empty(shape, dtype=dt))
+    sd = {k: synth.synth_tensor(k, torch.empty(shape, dtype=dt), conditioned)
           for k, (shape, dt) in model_spec.state_spec(rep_size, dc=dc).items()}
     sd = RM.leaf_state_dict(sd, opt)
     model = RM.RefRepDepth(sd, opt)
     tr = RM.RefTrainer(model, opt)
-    inputs = synth.make_inputs(B, H, W, intrinsics=intrinsics)
+    inputs = (synth.make_rendered_inputs(B, H, W, intrinsics=intrinsics) if conditioned
+              else synth.make_inputs(B, H, W, intrinsics=intrinsics))
     torch.manual_seed(seed)
     random.seed(seed)
     outputs, losses = tr.process_batch(inputs)
@@ -221,6 +222,14 @@ def test_e2e_small_checkpoint_semantics(golden):
 def test_e2e_full(golden):
     g = golden("e2e_full")
     _check_e2e(g, *_run_e2e(g))
+
+
+@pytest.mark.slow
+def test_e2e_rendered_well_conditioned(golden):
+    """The well-conditioned fixture (rendered frames, near-identity trunk, predicted pose = rendered pose) the bf16 step
+    is pinned on: the oracle reproduces the reference's unmodified process_batch on it like on the others."""
+    g = golden("e2e_render")
+    _check_e2e(g, *_run_e2e(g, conditioned=True))
 
 
 def test_e2e_replknet31l(golden):

@@ -40,18 +40,22 @@ class Replay:
         self.cur.setdefault(i, {})[self.rank] = t.detach().clone()
         return [t if r == self.rank else self.prev.get(i, {}).get(r, t) for r in range(self.world)]
 
-    def gather(self, packed, group):
-        return torch.stack(self._slot(packed)).contiguous()
+    def gather(self, table, group):                        # in place: this rank's row arrives filled
+        rows = self._slot(table[self.rank])
+        for r in range(self.world):
+            if r != self.rank:
+                table[r].copy_(rows[r])
 
     def reduce(self, sums, group):
         rows = self._slot(sums)
-        sums.copy_(torch.stack(rows).sum(0) / self.world)
+        sums.copy_(torch.stack(rows).sum(0))
 
     def install(self, monkeypatch):
         from ppeadepth import batchnorm, ops
         monkeypatch.setattr(ops, "gather_rows", self.gather)
         monkeypatch.setattr(ops, "reduce_sums", self.reduce)
         monkeypatch.setattr(ops, "sync_world", lambda group: self.world)
+        monkeypatch.setattr(ops, "sync_rank", lambda group: self.rank)
         monkeypatch.setattr(batchnorm, "_collectives_on", lambda: True)
 
 
