@@ -233,42 +233,286 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
     }
 }
 
-// tile choice of the dispatch below as (rows per workgroup, waves along the pixels): the statistics epilogue writes one
-// partial per pixel-wave, and the caller sizes / reduces that buffer
-void pw_config(int B, int M, int K, int HW, int& bm, int& wn) {
+// ---------------------------------------------------------------------------------------------------------------------
+// v2: the same GEMM with a three-stage LDS ring filled by LDS-DMA (`global_load_lds`, 16 bytes per lane, no staging
+// registers), counted `s_waitcnt vmcnt(N)` + ONE raw `s_barrier` per K step (two K tiles in flight across it), an
+// XCD-aware tile order and 16-byte epilogue stores.
+//   * LDS-DMA writes wave-uniform base + lane * 16, so both tiles are dense images and every swizzle sits on the SOURCE
+//     address (the inverse permutation of the fragment reads):
+//       X tile [BK k][128 pixels] (256-byte rows): 16-byte slot s of row r holds pixel chunk s ^ (2 (r & 3) + 8 ((r >> 3) & 1))
+//         -- the 8-byte swizzle of v1, which is a multiple of two 8-byte chunks; read with `ds_read_b64_tr_b16`;
+//       A tile [BM m][BK k] (128- / 64-byte rows): slot s of row r holds k chunk s ^ ((r >> 1) & 7)  /  s ^ (2 ((r >> 2) & 1));
+//         read with `ds_read_b128` (conflict free for its four 16-lane service groups, MI355X_MICROARCH.md LDS).
+//   * a wave waits for ITS loads of stage t (vmcnt leaves the newer stage in flight), the barrier publishes all four
+//     waves' pieces and retires everybody's reads of stage t - 1, whose buffer the loads for stage t + 2 then overwrite.
+//   * epilogue: `v_permlane16_swap` between the packed results of two neighbouring 16-pixel tiles gives every lane 8
+//     consecutive pixels of one channel: one 16-byte store instead of two 8-byte ones (a wave writes 64 contiguous bytes
+//     per channel row).
+// Requirements: K % BK == 0, HW % 8 == 0, A row-major [M][K] (the transposed-A mode stays on v1).
+constexpr int NSTAGE = 3;
+
+template <int BK> __device__ __forceinline__ int a_swz16(int row) {
+    return BK == 64 ? ((row >> 1) & 7) : (2 * ((row >> 2) & 1));
+}
+
+template <int BM, int BK, int EPI>
+__global__ __launch_bounds__(256) void pwconv2_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ X,
+                                                      const void* __restrict__ bias, int bias_bf16,
+                                                      const uint16_t* __restrict__ aux, uint16_t* __restrict__ Y,
+                                                      uint16_t* __restrict__ Y2, int M, int K, int HW, int nb, int mtiles,
+                                                      int total) {
+    constexpr int WM = BM >= 64 ? 2 : 1, WN = 4 / WM;
+    constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
+    constexpr int ARB = BK * 2;                          // bytes per A row
+    constexpr int A_BYTES = BM * ARB, X_BYTES = BK * B_STRIDE, STAGE = A_BYTES + X_BYTES;
+    constexpr int A_INS = A_BYTES / 1024 / 4, X_INS = X_BYTES / 1024 / 4;      // LDS-DMA instructions per wave and stage
+    static_assert(A_BYTES % 4096 == 0 && X_BYTES % 4096 == 0, "every wave issues the same number of loads per stage");
+    constexpr int LPS = A_INS + X_INS, KH = BK / 32;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+    // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2); give every XCD a
+    // contiguous run of logical tiles, channel tiles fastest, so the workgroups that share an X tile share an L2
+    const int id = blockIdx.x, xcd = id & 7, q8 = total >> 3, r8 = total & 7;
+    const int L = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    const int mt_i = L % mtiles, pt = L / mtiles;
+    const int n = pt / nb, p0 = (pt - n * nb) * BN, m0 = mt_i * BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const uint16_t* Xn = X + (long)n * K * HW;
+
+    // ---- LDS-DMA source addresses (per lane; advanced by BK channels per stage) and destinations (wave uniform) ----------
+    const uint16_t* a_src[A_INS];
+    const uint16_t* x_src[X_INS];
+#pragma unroll
+    for (int c = 0; c < A_INS; ++c) {
+        const int t = c * 4 + wave;                              // 1-KiB piece of the A tile
+        const int row = t * (1024 / ARB) + lane / (ARB / 16), slot = lane % (ARB / 16);
+        const int m = min(m0 + row, M - 1);                      // rows past M: any valid row (their outputs are not stored)
+        a_src[c] = A + (long)m * K + 8 * (slot ^ a_swz16<BK>(row));
+    }
+#pragma unroll
+    for (int c = 0; c < X_INS; ++c) {
+        const int t = c * 4 + wave;
+        const int row = 4 * t + (lane >> 4), slot = lane & 15;
+        int p = p0 + 8 * (slot ^ (2 * (row & 3) + 8 * ((row >> 3) & 1)));
+        if (p >= HW) p = p0;                                     // chunks past the plane: any valid chunk (not stored)
+        x_src[c] = Xn + (long)row * HW + p;
+    }
+    // LDS-DMA through inline asm: hipcc's wait-count pass would otherwise drain EVERY pending LDS-DMA (`vmcnt(0)`) in front of
+    // the first transposing LDS read after an issue -- it cannot tell the stage being filled from the stage being read --
+    // which is the whole pipeline.  M0 (the LDS destination base) is written in the statement that uses it and restored.
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    auto glds16 = [&](const uint16_t* src, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    };
+    auto issue = [&](int kt, int stage) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE + wave * 1024);
+        const long ka = (long)kt * BK, kx = (long)kt * BK * HW;
+#pragma unroll
+        for (int c = 0; c < A_INS; ++c) glds16(a_src[c] + ka, base + c * 4096);
+#pragma unroll
+        for (int c = 0; c < X_INS; ++c) glds16(x_src[c] + kx, base + A_BYTES + c * 4096);
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets inside a stage
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int b_rowi = 8 * g + q, b_s = b_swz(b_rowi);
+    int a_off[MT][KH];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int h = 0; h < KH; ++h) {
+            const int row = wm * TM + 16 * i + li;
+            a_off[i][h] = row * ARB + 16 * ((4 * h + g) ^ a_swz16<BK>(row));
+        }
+    const int x_off = A_BYTES + b_rowi * B_STRIDE;
+
+    const int nk = K / BK;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(kt + 2, cur >= 1 ? cur - 1 : NSTAGE - 1);       // (cur + 2) % 3: the buffer read one step ago
+        const uint8_t* buf = lds + cur * STAGE;
+#pragma unroll
+        for (int h = 0; h < KH; ++h) {
+            bf16x8 af[MT], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + a_off[i][h]));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int chunk = (((wn * TN + 16 * j) >> 2) + pp) ^ b_s;
+                const uint8_t* bp = buf + x_off + h * 32 * B_STRIDE + (chunk << 3);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp + 4 * B_STRIDE));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bfr[j] = __builtin_bit_cast(bf16x8, both);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        cur = cur == NSTAGE - 1 ? 0 : cur + 1;
+    }
+
+    // ---- epilogue: transposed C layout (col = lane & 15 = channel, rows 4 g + r = pixels); pairs of pixel tiles exchange
+    // halves so that a lane stores 8 consecutive pixels
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * TM + 16 * i + li;
+        const bool m_ok = m < M;
+        float bv = 0.f;
+        if (bias != nullptr && m_ok)
+            bv = bias_bf16 ? bf2f(reinterpret_cast<const uint16_t*>(bias)[m]) : reinterpret_cast<const float*>(bias)[m];
+        float st_s = 0.f, st_q = 0.f;
+        uint2 v[NT], w[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int p = p0 + wn * TN + 16 * j + 4 * g;
+            const bool ok = m_ok && p < HW;
+            const long o = (long)n * M * HW + (long)m * HW + p;
+            uint16_t e[4], f[4] = {0, 0, 0, 0};
+            if constexpr (EPI == 2) {
+                uint2 a = make_uint2(0, 0);
+                if (ok) a = *reinterpret_cast<const uint2*>(aux + o);
+                const uint16_t x[4] = {(uint16_t)(a.x & 0xffffu), (uint16_t)(a.x >> 16), (uint16_t)(a.y & 0xffffu),
+                                       (uint16_t)(a.y >> 16)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e[r] = f2bf(acc[i][j][r] * dgelu_f(bf2f(x[r])));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = f2bf(acc[i][j][r] + bv);
+                    if constexpr (EPI == 1) f[r] = f2bf(gelu_f(bf2f(e[r])));
+                    if constexpr (EPI == 4) {
+                        if (ok) { const float t = bf2f(e[r]); st_s += t; st_q += t * t; }
+                    }
+                }
+            }
+            v[j] = make_uint2(e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16));
+            w[j] = make_uint2(f[0] | ((uint32_t)f[1] << 16), f[2] | ((uint32_t)f[3] << 16));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; j += 2) {
+            // rows 1 / 3 of tile j <-> rows 0 / 2 of tile j + 1: lane group g then holds pixels 8 (g >> 1) .. + 7 of tile
+            // j + (g & 1), the first four in the tile-j register, the next four in the tile-(j + 1) register
+            auto sx = __builtin_amdgcn_permlane16_swap(v[j].x, v[j + 1].x, false, false);
+            auto sy = __builtin_amdgcn_permlane16_swap(v[j].y, v[j + 1].y, false, false);
+            const int p = p0 + wn * TN + 16 * (j + (g & 1)) + 8 * (g >> 1);
+            const long o = (long)n * M * HW + (long)m * HW + p;
+            if (m_ok && p < HW) *reinterpret_cast<uint4*>(Y + o) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            if constexpr (EPI == 1) {
+                auto tx = __builtin_amdgcn_permlane16_swap(w[j].x, w[j + 1].x, false, false);
+                auto ty = __builtin_amdgcn_permlane16_swap(w[j].y, w[j + 1].y, false, false);
+                if (m_ok && p < HW) *reinterpret_cast<uint4*>(Y2 + o) = make_uint4(tx[0], ty[0], tx[1], ty[1]);
+            }
+        }
+        if constexpr (EPI == 4) {
+            st_s += __shfl_xor(st_s, 16, WAVE); st_q += __shfl_xor(st_q, 16, WAVE);
+            st_s += __shfl_xor(st_s, 32, WAVE); st_q += __shfl_xor(st_q, 32, WAVE);
+            if (g == 0 && m_ok) {
+                const long P = (long)(total / mtiles) * WN;
+                float* sp = reinterpret_cast<float*>(Y2) + ((long)m * P + (long)pt * WN + wn) * 2;
+                sp[0] = st_s; sp[1] = st_q;
+            }
+        }
+    }
+}
+
+// ---- dispatch ----------------------------------------------------------------------------------------------------------
+// One place decides the kernel and its tile: the statistics epilogue writes one partial per pixel-wave (WN), and
+// ppea_pwconv_stats_partials must size that buffer for the kernel that will run.
+struct PwCfg { int v2, bm, bk, wn; };
+
+PwCfg pw_choose(int B, int M, int K, int HW, bool ta) {
     const int nb = (HW + BN - 1) / BN;
     const long blocks128 = (long)nb * ((M + 127) / 128) * B, blocks64 = (long)nb * ((M + 63) / 64) * B;
-    static const char* force = getenv("PPEA_PW_TILE");
-    if (force != nullptr) bm = atoi(force) == 128 ? 128 : (atoi(force) == 64 ? 64 : 32);
-    else bm = (M >= 128 && blocks128 >= 512) ? 128 : ((M > 32 && blocks64 >= 256) ? 64 : 32);
-    wn = bm == 32 ? 4 : 2;
+    PwCfg c;
+    // tuning / test hooks, read per call so that a test can walk the tiles in one process
+    const char* force = getenv("PPEA_PW_TILE");                 // v1 tile: "128", "64", "32" [+ "d" = 64-channel steps]
+    const char* v2env = getenv("PPEA_PW_V2");                   // "0": v1 everywhere; "bm,bk": force a v2 tile
+    if (force != nullptr) {
+        c.bm = atoi(force) == 128 ? 128 : (atoi(force) == 64 ? 64 : 32);
+        c.bk = strchr(force, 'd') != nullptr ? 64 : 32;
+    } else {
+        c.bm = (M >= 128 && blocks128 >= 512) ? 128 : ((M > 32 && blocks64 >= 256) ? 64 : 32);
+        // 64 channels per step only where it pays (measured on v1): long contraction AND too few tiles to hide the
+        // per-step latency by occupancy
+        c.bk = (c.bm != 128 && K >= 512) ? 64 : 32;
+    }
+    c.v2 = 0;
+    if (!ta && !(v2env != nullptr && v2env[0] == '0' && v2env[1] == 0)) {
+        // measured per trunk shape (tools/bench_pw4.py, profiles/r03_pwconv_shapes.txt): enough 128-row tiles to fill the
+        // chip once -> 128 x 128 tiles with 32-channel steps (48 KB of LDS: three workgroups per CU hide each other's
+        // barriers); else 64-row tiles (64-channel steps for long contractions); else 32-row tiles with 64-channel steps
+        int bm, bk;
+        if (M >= 128 && blocks128 >= 256) { bm = 128; bk = 32; }
+        else if (M > 32 && blocks64 >= 256) { bm = 64; bk = (K >= 512 && K % 64 == 0) ? 64 : 32; }
+        else if (K % 64 == 0) { bm = 32; bk = 64; }
+        else { bm = 64; bk = 32; }
+        if (v2env != nullptr && strchr(v2env, ',') != nullptr) { bm = atoi(v2env); bk = atoi(strchr(v2env, ',') + 1); }
+        if (bm == 32 && bk == 32) bk = 64;                       // a 32 x 32 A tile is half a piece per wave
+        if ((bm == 128 || bm == 64 || bm == 32) && (bk == 64 || bk == 32) && K % bk == 0) { c.v2 = 1; c.bm = bm; c.bk = bk; }
+    }
+    c.wn = c.bm == 32 ? 4 : 2;
+    return c;
+}
+
+template <int BM, int BK, int EPI>
+int launch_pw2_t(const void* A, const void* X, const void* bias, int bias_bf16, const void* aux, void* Y, void* Y2, int B,
+                 int M, int K, int HW, hipStream_t st) {
+    constexpr int smem = NSTAGE * (BM * BK * 2 + BK * B_STRIDE);
+    static bool ready = false;                                   // per instantiation
+    auto kern = pwconv2_kernel<BM, BK, EPI>;
+    if (!ready) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+        ready = true;
+    }
+    const int nb = (HW + BN - 1) / BN, mtiles = (M + BM - 1) / BM;
+    const long total = (long)nb * mtiles * B;
+    if (total > 0x7fffffffL) return PPEA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), smem, st, (const uint16_t*)A, (const uint16_t*)X, bias, bias_bf16,
+                       (const uint16_t*)aux, (uint16_t*)Y, (uint16_t*)Y2, M, K, HW, nb, mtiles, (int)total);
+    return launch_status();
 }
 
 template <int EPI, bool TA>
 int launch_pw(const void* A, const void* X, const void* bias, int bias_bf16, const void* aux, void* Y, void* Y2, int B,
               int M, int K, int HW, hipStream_t st) {
+    const PwCfg c = pw_choose(B, M, K, HW, TA);
+    if constexpr (!TA) {
+        if (c.v2) {
+#define PW2(BM_, BK_) return launch_pw2_t<BM_, BK_, EPI>(A, X, bias, bias_bf16, aux, Y, Y2, B, M, K, HW, st)
+            if (c.bm == 128) { if (c.bk == 64) PW2(128, 64); else PW2(128, 32); }
+            if (c.bm == 64) { if (c.bk == 64) PW2(64, 64); else PW2(64, 32); }
+            PW2(32, 64);
+#undef PW2
+        }
+    }
     const int nb = (HW + BN - 1) / BN;
-    const long blocks128 = (long)nb * ((M + 127) / 128) * B;
 #define PW_LAUNCH(BM_, WM_, WN_, BK_)                                                                                 \
     hipLaunchKernelGGL((pwconv_kernel<BM_, WM_, WN_, EPI, TA, BK_>), dim3(nb, (M + BM_ - 1) / BM_, B), dim3(256), 0, st, \
                        (const uint16_t*)A, (const uint16_t*)X, bias, bias_bf16, (const uint16_t*)aux, (uint16_t*)Y, \
                        (uint16_t*)Y2, M, K, HW)
-    const long blocks64 = (long)nb * ((M + 63) / 64) * B;
-    // 64 channels per step only where it pays (measured): long contraction AND too few tiles to hide the per-step
-    // latency by occupancy; with plenty of tiles the smaller LDS footprint (more workgroups per CU) wins.
-    const bool deep = K >= 512;
-    static const char* force = getenv("PPEA_PW_TILE");          // tuning hook (tools/bench_pw2.py): "128", "64", "32" [+ "d"]
-    if (force != nullptr) {
-        const int bm = atoi(force);
-        const bool dp = strchr(force, 'd') != nullptr;
-        if (bm == 128) PW_LAUNCH(128, 2, 2, 32);
-        else if (bm == 64) { if (dp) PW_LAUNCH(64, 2, 2, 64); else PW_LAUNCH(64, 2, 2, 32); }
-        else { if (dp) PW_LAUNCH(32, 1, 4, 64); else PW_LAUNCH(32, 1, 4, 32); }
-        return launch_status();
-    }
-    if (M >= 128 && blocks128 >= 512) PW_LAUNCH(128, 2, 2, 32);
-    else if (M > 32 && blocks64 >= 256) { if (deep) PW_LAUNCH(64, 2, 2, 64); else PW_LAUNCH(64, 2, 2, 32); }
-    else { if (deep) PW_LAUNCH(32, 1, 4, 64); else PW_LAUNCH(32, 1, 4, 32); }   // few tiles: smaller workgroups
+    if (c.bm == 128) PW_LAUNCH(128, 2, 2, 32);
+    else if (c.bm == 64) { if (c.bk == 64) PW_LAUNCH(64, 2, 2, 64); else PW_LAUNCH(64, 2, 2, 32); }
+    else { if (c.bk == 64) PW_LAUNCH(32, 1, 4, 64); else PW_LAUNCH(32, 1, 4, 32); }
 #undef PW_LAUNCH
     return launch_status();
 }
@@ -291,9 +535,7 @@ int ppea_pwconv_bf16(const void* A, const void* X, const float* bias, void* Y, i
 // pairs, stats [M][P][2] fp32 (every entry written; reduce with ppea_bn_finalize_sums_f32).
 int ppea_pwconv_stats_partials(int B, int M, int K, int HW) {
     if (B <= 0 || M <= 0 || K <= 0 || HW <= 0) return 0;
-    int bm, wn;
-    pw_config(B, M, K, HW, bm, wn);
-    return B * ((HW + BN - 1) / BN) * wn;
+    return B * ((HW + BN - 1) / BN) * pw_choose(B, M, K, HW, false).wn;
 }
 int ppea_pwconv_stats_bf16(const void* A, const void* X, const float* bias, void* Y, float* stats, int B, int M, int K,
                            int HW, void* stream) {

@@ -449,6 +449,62 @@ def test_pwconv_mfma(device, B, M, K, H, W):
     assert (xd.grad.float().cpu() - gref).abs().max() <= gref.abs().max() * 2 ** -7
 
 
+@pytest.mark.parametrize("tile", ["128,64", "128,32", "64,64", "64,32", "32,64"])
+@pytest.mark.parametrize("B,M,K,H,W", [(2, 256, 128, 48, 160), (3, 512, 256, 12, 40), (2, 200, 192, 24, 80),
+                                       (3, 96, 512, 6, 20), (1, 1024, 1024, 5, 8), (5, 64, 64, 13, 8)])
+def test_pwconv_v2_lds_dma_ring_every_tile(device, monkeypatch, tile, B, M, K, H, W):
+    """pwconv v2 (three-stage LDS ring filled by LDS-DMA, counted vmcnt, XCD-aware tile order, 16-byte epilogue stores),
+    every tile shape forced in turn: plain / bias, the GELU epilogue (pre-activation + activation), the GELU' epilogue and
+    the BatchNorm-statistics epilogue against the fp32 product of the bf16-rounded operands and against v1 (identical
+    rounding points: equal to the last bf16 bit up to fp32 summation order); ragged channel tiles (M % BM != 0), planes
+    that are not a multiple of the 128-pixel tile, K of 1-16 steps."""
+    import os
+    from ppeadepth import _abi, ops
+    bk = int(tile.split(",")[1])
+    if K % bk:
+        pytest.skip("tile needs K % BK == 0 (the dispatch then takes another tile)")
+    g = _g(M + K + H)
+    x = torch.randn(B, K, H, W, generator=g).bfloat16().to(device)
+    a = (torch.randn(M, K, generator=g) / K ** 0.5).bfloat16().to(device)
+    bias = torch.randn(M, generator=g).to(device)
+    aux = torch.randn(B, M, H, W, generator=g).bfloat16().to(device)
+    ref = torch.einsum("mk,bkhw->bmhw", a.float(), x.float())
+    ptr, sp = _abi.ptr, _abi.stream_ptr
+
+    def run():
+        y0 = ops.pwconv_raw(a, x, bias)
+        pre, act = ops.pwconv_ex(a, x, bias, ops.EPI_GELU)
+        dg = ops.pwconv_ex(a, x, None, ops.EPI_DGELU, aux)
+        P = _abi.lib.ppea_pwconv_stats_partials(B, M, K, H * W)
+        ys = torch.empty(B, M, H, W, device=device, dtype=torch.bfloat16)
+        sums = torch.full((M, P, 2), float("nan"), device=device)
+        _abi.call("ppea_pwconv_stats_bf16", ptr(a), ptr(x), None, ptr(ys), ptr(sums), B, M, K, H * W, sp())
+        return y0, pre, act, dg, ys, sums
+
+    monkeypatch.setenv("PPEA_PW_V2", tile)
+    y0, pre, act, dg, ys, sums = run()
+    monkeypatch.setenv("PPEA_PW_V2", "0")
+    v1 = run()
+    monkeypatch.delenv("PPEA_PW_V2")
+    tol = 2 ** -7
+    refb = ref + bias.view(1, -1, 1, 1)
+    assert (y0.float() - refb).abs().max() <= refb.abs().max() * tol
+    assert torch.equal(pre, y0)
+    assert (act.float() - torch.nn.functional.gelu(pre.float())).abs().max() <= 2 ** -7 * act.float().abs().max()
+    xa = aux.float()
+    dgelu = 0.5 * (1 + torch.erf(xa / 2 ** 0.5)) + xa * torch.exp(-0.5 * xa * xa) / (2 * torch.pi) ** 0.5
+    assert (dg.float() - ref * dgelu).abs().max() <= (ref * dgelu).abs().max() * tol
+    assert (ys.float() - ref).abs().max() <= ref.abs().max() * tol
+    tot = sums.double().sum(1)
+    assert torch.isfinite(tot).all()
+    assert rel_err(tot[:, 0].float(), ys.float().sum((0, 2, 3))) < 1e-5
+    assert rel_err(tot[:, 1].float(), (ys.float() ** 2).sum((0, 2, 3))) < 1e-5
+    for mine, old in zip((y0, act, dg, ys), (v1[0], v1[2], v1[3], v1[4])):
+        # same operands, same rounding points; only the fp32 summation order inside a K step may differ
+        assert (mine.float() - old.float()).abs().max() <= old.float().abs().max() * 2 ** -7
+        assert (mine != old).float().mean() < 0.02
+
+
 @pytest.mark.parametrize("B,M,N,H,W", [(2, 128, 128, 12, 40), (3, 288, 128, 48, 160), (2, 100, 36, 6, 20),
                                        (12, 1152, 512, 12, 40), (1, 32, 256, 3, 8)])
 def test_pwgrad_mfma(device, B, M, N, H, W):
