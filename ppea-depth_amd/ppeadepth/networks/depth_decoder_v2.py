@@ -27,6 +27,25 @@ class Adapter(nn.Module):
         from .replknet_adapter import channel_linear
         return channel_linear(self.act(channel_linear(x, self.D_fc1)), self.D_fc2)
 
+    def forward_split(self, fine, coarse, factor):
+        """Adapter(cat([fine, nearest_upsample(coarse, factor)], 1)) without building the concatenation (dec.py:230-233
+        feeds 128 + 1024 channels at 1/4 resolution): D_fc1 is linear over channels and nearest upsampling only repeats
+        pixels, so  W1 [fine | up(coarse)] = W1a fine + up(W1b coarse)  -- the coarse half of the GEMM runs on the 1/32
+        map (64x fewer pixels).  bf16 step: both halves, D_fc2 and every gradient on the pwconv / pwgrad kernels (hidden
+        148 zero-padded to 160); None when this call is not served."""
+        from .. import ops
+        from . import replknet_adapter as rka
+        Cf = fine.shape[1]
+        if not (rka.ADAPTER_MFMA and fine.is_cuda and fine.dtype == torch.bfloat16 and coarse.dtype == torch.bfloat16
+                and ops.pw_linear_supported(fine, 32) and ops.pw_linear_supported(coarse, 32)
+                and self.D_fc2.out_features % 8 == 0):
+            return None
+        w1, b1, w2 = ops._pad_hidden(self.D_fc1.weight, self.D_fc1.bias, self.D_fc2.weight)
+        pre = ops.pw_linear(fine.contiguous(), w1[:, :Cf].contiguous(), b1)
+        pre = pre + F.interpolate(ops.pw_linear(coarse.contiguous(), w1[:, Cf:].contiguous()), scale_factor=factor,
+                                  mode="nearest").to(pre.dtype)
+        return ops.pw_linear(self.act(pre).to(torch.bfloat16), w2, self.D_fc2.bias)
+
 
 class DepthDecoderV2(nn.Module):
     def __init__(self, num_ch_enc, scales=range(4), debug=False, num_output_channels=1, use_skips=True,
@@ -62,21 +81,28 @@ class DepthDecoderV2(nn.Module):
 
     def forward(self, input_features):
         self.outputs = {}
-        if NHWC and input_features[-1].is_cuda and not self.dc:
-            # the decoder's 3x3 convolutions run on the library's NHWC-native implicit-GEMM kernels: hand them
+        adpt_out = None
+        if self.dc:
+            from .. import ops
+            # Stage-2 decoder adapter (dec.py:178-182, 230-233) on the NCHW encoder features
+            a = self.adapter.forward_split(input_features[0], input_features[-1], 8)
+            if a is None:
+                x_up = F.interpolate(input_features[-1], scale_factor=8, mode="nearest")
+                a = self.adapter(torch.cat([input_features[0], x_up], 1))
+            adpt_out = ops.conv_transpose_module(self.deconv_adpt, a)
+            if adpt_out is None:
+                adpt_out = self.deconv_adpt(a)
+        if NHWC and input_features[-1].is_cuda:
+            # the decoder's 3x3 convolutions are implicit GEMMs over channels-last operands (csrc/conv_nhwc.hip): hand them
             # channels_last activations once here (pad / bias + ELU have channels_last kernels, upsample and concat keep
             # the format) instead of a layout round trip around every convolution
             input_features = [f.contiguous(memory_format=torch.channels_last) for f in input_features]
         x = input_features[-1]
-        adpt_out = None
-        if self.dc:
-            x_up = F.interpolate(x, scale_factor=8, mode="nearest")
-            adpt_out = self.deconv_adpt(self.adapter(torch.cat([input_features[0], x_up], 1)))
         for i in range(4):
             x = upsample_cat(self.upconvs_0[i](x), input_features[2 - i] if i < 3 else None)
             x = self.upconvs_1[i](x)
         x = self.upconvs_1[-1](upsample_cat(self.upconvs_0[-1](x)))
         if self.dc:
-            x = x + F.interpolate(adpt_out, scale_factor=2)
+            x = x + F.interpolate(adpt_out, scale_factor=2).to(x.dtype)    # (autocast runs the interpolation in fp32)
         self.outputs[("disp", 0)] = self.disp_convs[0](x, act="sigmoid")          # sigmoid in the conv's epilogue
         return self.outputs

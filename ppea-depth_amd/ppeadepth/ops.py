@@ -1206,9 +1206,24 @@ def tapsum_bwd(g):
 
 
 def adapter_supported(x, hidden):
+    """Any hidden width is served: mlp_adapter / conv_adapter zero-pad it to the next multiple of 32 (RepLKNet-31L stage 0:
+    hidden 48; the Stage-2 decoder adapter: 148)."""
     B, C, H, W = x.shape
-    return (x.is_cuda and x.dtype == _BF16 and C % 32 == 0 and hidden % 32 == 0 and (H * W) % 8 == 0
-            and W % 4 == 0)
+    return (x.is_cuda and x.dtype == _BF16 and C % 32 == 0 and hidden >= 1 and (H * W) % 8 == 0 and W % 4 == 0)
+
+
+def _pad_hidden(w1, b1, w2):
+    """Zero rows for D_fc1 / zero columns for D_fc2 up to a hidden width the GEMM kernels take (a multiple of 32).  The
+    padded units compute gelu(0) = 0 and meet zero columns: same function, same gradients (autograd slices the padded
+    gradients back); three small concatenations per call."""
+    Ch = w1.shape[0]
+    pad = (-Ch) % 32
+    if pad == 0:
+        return w1, b1, w2
+    w1p = torch.cat([w1, w1.new_zeros((pad,) + tuple(w1.shape[1:]))], 0)
+    b1p = None if b1 is None else torch.cat([b1, b1.new_zeros(pad)], 0)
+    w2p = torch.cat([w2, w2.new_zeros(w2.shape[0], pad)], 1)
+    return w1p, b1p, w2p
 
 
 def _grad_dtype(t):
@@ -1277,11 +1292,102 @@ class _ConvAdapterFn(torch.autograd.Function):
 
 
 def mlp_adapter(x, w1, b1, w2, b2):
+    w1, b1, w2 = _pad_hidden(w1, b1, w2)
     return _MlpAdapterFn.apply(x, w1, b1, w2, b2)
 
 
 def conv_adapter(x, w1, b1, w2, b2):
+    w1, b1, w2 = _pad_hidden(w1, b1, w2)
     return _ConvAdapterFn.apply(x, w1, b1, w2, b2)
+
+
+class _PwLinear(torch.autograd.Function):
+    """y[b, :, p] = W x[b, :, p] (+ bias) over the channel axis of NCHW bf16 x with a TRAINABLE W [M, K]: forward and data
+    gradient on pwconv (the data gradient consumes W through the kernel's transposed-A mode), weight / bias gradients on
+    pwgrad, written in parameter dtype."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        wm = w.to(_BF16).contiguous()
+        y = pwconv_ex(wm, x, b)
+        ctx.save_for_backward(x, wm)
+        ctx.meta = (tuple(w.shape), _grad_dtype(w), None if b is None else _grad_dtype(b))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wm = ctx.saved_tensors
+        wshape, wdt, bdt = ctx.meta
+        dy = dy.contiguous().to(_BF16)
+        dx = pwconv_ex(wm, dy, transposed=True) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (bdt is not None and ctx.needs_input_grad[2]):
+            dw, db = pwgrad_into(dy, x, wshape, wdt, 1, None if bdt is None else (0, wshape[0]), bdt)
+        return dx, dw, db
+
+
+def pw_linear_supported(x, M):
+    B, K, H, W = x.shape
+    return x.is_cuda and x.dtype == _BF16 and K % 32 == 0 and M % 8 == 0 and (H * W) % 8 == 0
+
+
+def pw_linear(x, w, b=None):
+    """nn.Linear(K -> M) over the channel axis of x [B,K,H,W] bf16 -> [B,M,H,W] (trainable weight and bias)."""
+    return _PwLinear.apply(x, w, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# A13  transposed convolution of the Stage-2 decoder adapter (depth_decoder_v2.py:137-139: ConvTranspose2d(c, c, 3, 2, 1,
+# output_padding=1)) on the implicit-GEMM kernels: the forward IS the data gradient of a stride-2 conv, its data gradient is
+# that conv's forward, its weight gradient that conv's weight gradient with the two activations exchanged.
+# ---------------------------------------------------------------------------------------------
+class _ConvTransposeNhwc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, out_pad):
+        x = _as_nhwc(x)
+        N, Cin, H, W = x.shape
+        _, Cout, R, S = w.shape                                  # ConvTranspose2d weight: [Cin, Cout, R, S]
+        Ho, Wo = (H - 1) * stride - 2 * pad + R + out_pad, (W - 1) * stride - 2 * pad + S + out_pad
+        # as a conv weight [Cout_c = Cin][Cin_c = Cout][R][S]: the flipped / transposed operand image of its data gradient
+        y = conv_nhwc_raw(x, _conv_packed(w, True), None if bias is None else bias.detach().contiguous(), Cout, R, S, 1,
+                          R - 1 - pad, False, stride, Ho, Wo, 0, False)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, Ho, Wo, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, Ho, Wo, bdt = ctx.cfg
+        N, Cin, H, W = x.shape
+        _, Cout, R, S = w.shape
+        dz = _as_nhwc(dy.to(_BF16))
+        db = dz.float().sum((0, 2, 3)).to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
+        dx = dw = None
+        if ctx.needs_input_grad[0]:                              # = conv2d(dy, w as [Cin][Cout][R][S], stride, pad)
+            dx = conv_nhwc_raw(dz, _conv_packed(w, False), None, Cin, R, S, stride, pad, False, 1, H, W, 0, False)
+        if ctx.needs_input_grad[1]:
+            if Cin % 8 != 0 or Cout % 8 != 0:
+                raise _abi.PpeaKernelError("transposed conv weight gradient: channels must be multiples of 8")
+            # weight gradient of that conv: "input" = dy [N,Cout,Ho,Wo], "output gradient" = x [N,Cin,H,W]
+            ws = torch.empty(_abi.lib.ppea_conv_wgrad_workspace_bytes(N, Cout, Cin, R, S, stride, H, W) // 4, device=dz.device,
+                             dtype=_F32)
+            gdt = w.dtype if w.dtype in (_BF16, _F32) else _F32
+            dw = torch.empty(Cin, Cout, R, S, device=dz.device, dtype=gdt)
+            call("ppea_conv_wgrad_nhwc_bf16", _raw(x), _raw(dz), ptr(dw), int(gdt == _BF16), ptr(ws), N, Ho, Wo, Cout, Cin, R, S,
+                 stride, pad, 0, H, W, stream_ptr())
+        return dx, dw, db, None, None, None
+
+
+def conv_transpose_module(m, x):
+    """nn.ConvTranspose2d `m` on the implicit-GEMM kernels (bf16 step), or None when this call is not served."""
+    if not (CONV_MFMA and x.is_cuda and x.dtype == _BF16 and m.groups == 1 and tuple(m.dilation) == (1, 1)
+            and m.stride[0] == m.stride[1] and m.stride[0] in (1, 2) and m.kernel_size[0] == m.kernel_size[1] == 3
+            and m.padding[0] == m.padding[1] and m.output_padding[0] == m.output_padding[1]
+            and x.shape[1] % 8 == 0 and m.out_channels % 8 == 0):
+        return None
+    return _ConvTransposeNhwc.apply(x, m.weight, m.bias, m.stride[0], m.padding[0], m.output_padding[0])
 
 
 # ---------------------------------------------------------------------------------------------

@@ -346,6 +346,44 @@ def test_engine_step_bf16_on_the_rendered_fixture(device, golden):
         assert not bad, (graph, bad)
 
 
+@pytest.mark.parametrize("cfg", ["b", "l", "dc"])
+def test_bf16_step_launches_no_library_convolution_or_gemm(device, cfg):
+    """Every convolution / GEMM of the benchmarked step is a hand-written gfx950 kernel, for every BASELINE config: one
+    bf16 engine step of config 2 (31B), config 4 (31L: stage-0 adapters have hidden 48) and config 5 (`--dc`: decoder
+    adapter with hidden 148 + transposed conv) under the profiler; no MIOpen / CK / rocBLAS / hipBLASLt kernel may
+    appear except the tiny pose-algebra products (4x4 / 3x3 matrices: K @ T, Rodrigues), which are not convolutions."""
+    import re
+    from torch.profiler import ProfilerActivity, profile
+    from ppeadepth import rng
+    from ppeadepth.dist import TrainEngine
+    B, H, W = 1, 192, (512 if cfg == "dc" else 640)
+    opt, model, tr = _build(device, B, H, W, use_checkpoint=True, amp=torch.bfloat16, rep_size="l" if cfg == "l" else "b",
+                            dc=(cfg == "dc"), conditioned=True)
+    rng.set_mode("device")
+    eng = TrainEngine(tr, lr=1e-4, bf16_params=True)
+    inputs = {k: v.to(device) for k, v in synth.make_rendered_inputs(
+        B, H, W, intrinsics="cityscapes" if cfg == "dc" else "kitti").items()}
+    eng.step(dict(inputs))                                   # warm-up (lazy initialisations)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        _, losses = eng.step(dict(inputs))
+        torch.cuda.synchronize()
+    assert float(losses["loss"]) == float(losses["loss"])
+    names = {}
+    for ev in prof.events():
+        if str(ev.device_type).endswith("CUDA") and ev.name:
+            names[ev.name] = names.get(ev.name, 0) + 1
+    assert len(names) > 20, "the profiler recorded no device kernels"
+    lib = re.compile(r"Cijk_|igemm|ck::|ck_tile|miopen|MIOpen|naive_conv|SubTensorOp|gemm_|Gemm|wmma|batched_transpose")
+    hits = {n: c for n, c in names.items() if lib.search(n)}
+    gemms = sum(c for n, c in hits.items() if "Cijk_" in n)
+    others = {n: c for n, c in hits.items() if "Cijk_" not in n}
+    assert not others, others
+    assert gemms <= 16, hits                                  # pose algebra only (13 per step at the time of writing)
+    ours = sum(c for n, c in names.items() if "pwconv" in n or "conv_nhwc" in n or "dwconv_mfma" in n)
+    assert ours > 200
+
+
 def test_train_step_decreases_loss_and_bf16_runs(device):
     """A few optimizer steps on a fixed batch reduce the loss; the bf16-autocast step is finite."""
     from ppeadepth import rng

@@ -1151,3 +1151,114 @@ def test_block_chain_last_bn_plus_next_pre_bn_is_bit_identical(device, dtype="bf
         assert torch.equal(a[2][n], b[2][n]), n
     for n in a[3]:
         assert torch.equal(a[3][n], b[3][n]), n
+
+
+# ---- round 3: the remaining library holes ---------------------------------------------------------------
+@pytest.mark.parametrize("kind,C,hidden", [("mlp", 192, 48), ("conv", 192, 48), ("mlp", 128, 148), ("conv", 64, 20)])
+def test_adapters_with_ragged_hidden_width_run_on_the_mfma_kernels(device, kind, C, hidden):
+    """Hidden widths that are not a multiple of 32 (RepLKNet-31L stage 0: 48; the Stage-2 decoder adapter: 148) are
+    zero-padded to the next multiple: same function and gradients as the fp32 composite of the bf16-rounded operands."""
+    import torch.nn.functional as F
+    from ppeadepth import ops
+    B, H, W = 2, 12, 40
+    g = _g(C + hidden)
+    x = torch.randn(B, C, H, W, generator=g).bfloat16()
+    w1 = (torch.randn((hidden, C, 3, 3) if kind == "conv" else (hidden, C), generator=g) / (C * (9 if kind == "conv" else 1)) ** 0.5).bfloat16()
+    b1 = (torch.randn(hidden, generator=g) * 0.1).bfloat16()
+    w2 = (torch.randn(C, hidden, generator=g) / hidden ** 0.5).bfloat16()
+    b2 = (torch.randn(C, generator=g) * 0.1).bfloat16()
+    go = torch.randn(B, C, H, W, generator=g).bfloat16()
+    ref_leaves = [t.float().clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    xr, w1r, b1r, w2r, b2r = ref_leaves
+    pre = F.conv2d(xr, w1r, b1r, padding=1) if kind == "conv" else torch.einsum("mk,bkhw->bmhw", w1r, xr) + b1r.view(1, -1, 1, 1)
+    yr = torch.einsum("mk,bkhw->bmhw", w2r, F.gelu(pre)) + b2r.view(1, -1, 1, 1)
+    (yr * go.float()).sum().backward()
+    leaves = [t.to(device).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    assert ops.adapter_supported(leaves[0], hidden)
+    y = (ops.conv_adapter if kind == "conv" else ops.mlp_adapter)(*leaves)
+    (y.float() * go.to(device).float()).sum().backward()
+    assert (y.float().cpu() - yr.detach()).abs().max() <= yr.abs().max() * 2 ** -6
+    for mine, ref in zip(leaves, ref_leaves):
+        assert mine.grad.shape == ref.grad.shape
+        assert (mine.grad.float().cpu() - ref.grad).abs().max() <= ref.grad.abs().max() * 2 ** -5, mine.shape
+
+
+def test_pw_linear_trainable_forward_and_gradients(device):
+    from ppeadepth import ops
+    B, K, M, H, W = 3, 128, 160, 12, 40
+    g = _g(7)
+    x = torch.randn(B, K, H, W, generator=g).bfloat16()
+    w = (torch.randn(M, K, generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(M, generator=g).bfloat16()
+    go = torch.randn(B, M, H, W, generator=g).bfloat16()
+    xr, wr, br = (t.float().clone().requires_grad_(True) for t in (x, w, b))
+    yr = torch.einsum("mk,bkhw->bmhw", wr, xr) + br.view(1, -1, 1, 1)
+    (yr * go.float()).sum().backward()
+    xd, wd, bd = (t.to(device).requires_grad_(True) for t in (x, w, b))
+    assert ops.pw_linear_supported(xd, M)
+    y = ops.pw_linear(xd, wd, bd)
+    (y.float() * go.to(device).float()).sum().backward()
+    assert (y.float().cpu() - yr.detach()).abs().max() <= yr.abs().max() * 2 ** -7
+    for mine, ref in ((xd, xr), (wd, wr), (bd, br)):
+        assert (mine.grad.float().cpu() - ref.grad).abs().max() <= ref.grad.abs().max() * 2 ** -6
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 32, 48, 160), (1, 32, 5, 7), (2, 64, 12, 16)])
+def test_conv_transpose_on_the_implicit_gemm_kernels(device, N, C, H, W):
+    """ConvTranspose2d(C, C, 3, stride 2, padding 1, output_padding 1) (depth_decoder_v2.py:137-139): forward = the data
+    gradient kernel of a stride-2 conv, data gradient = that conv's forward, weight gradient = its weight gradient with
+    the activations exchanged; against torch's fp32 ConvTranspose2d on the bf16-rounded operands."""
+    import torch.nn as nn
+    from ppeadepth import ops
+    g = _g(N * 100 + C + H)
+    m = nn.ConvTranspose2d(C, C, 3, 2, 1, output_padding=1)
+    with torch.no_grad():
+        m.weight.copy_((torch.randn(m.weight.shape, generator=g) / (9 * C) ** 0.5).bfloat16().float())
+        m.bias.copy_((torch.randn(C, generator=g) * 0.1).bfloat16().float())
+    x = torch.randn(N, C, H, W, generator=g).bfloat16()
+    go = torch.randn(N, C, 2 * H, 2 * W, generator=g).bfloat16()
+    xr = x.float().clone().requires_grad_(True)
+    yr = m(xr)
+    (yr * go.float()).sum().backward()
+    ref = (yr.detach(), xr.grad.clone(), m.weight.grad.clone(), m.bias.grad.clone())
+    md = nn.ConvTranspose2d(C, C, 3, 2, 1, output_padding=1).to(device)
+    md.load_state_dict(m.state_dict())
+    md = md.bfloat16()
+    xd = x.to(device).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.conv_transpose_module(md, xd)
+    assert y is not None and tuple(y.shape) == (N, C, 2 * H, 2 * W)
+    (y.float() * go.to(device).float()).sum().backward()
+    got = (y.float().cpu(), xd.grad.float().cpu(), md.weight.grad.float().cpu(), md.bias.grad.float().cpu())
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and (a - b).abs().max() <= b.abs().max() * 2 ** -6
+
+
+def test_decoder_adapter_split_equals_the_concatenated_form(device):
+    """Adapter(cat([f0, up8(f3)])) == W1a f0 + up8(W1b f3) (+ GELU, D_fc2): the bf16 HIP form against the module's fp32
+    forward on the same (bf16-rounded) parameters, values and all parameter / input gradients."""
+    import torch.nn.functional as F
+    from ppeadepth.networks.depth_decoder_v2 import Adapter
+    B, Cf, Cc, h, w = 2, 128, 1024, 6, 16
+    g = _g(3)
+    ad = Adapter(Cf + Cc, 32)
+    with torch.no_grad():
+        for p in ad.parameters():
+            p.copy_((torch.randn(p.shape, generator=g) / max(p.shape[-1], 8) ** 0.5).bfloat16().float())
+    f0 = torch.randn(B, Cf, 8 * h, 8 * w, generator=g).bfloat16()
+    f3 = torch.randn(B, Cc, h, w, generator=g).bfloat16()
+    go = torch.randn(B, 32, 8 * h, 8 * w, generator=g).bfloat16()
+    a, b = f0.float().clone().requires_grad_(True), f3.float().clone().requires_grad_(True)
+    yr = ad(torch.cat([a, F.interpolate(b, scale_factor=8, mode="nearest")], 1))
+    (yr * go.float()).sum().backward()
+    ref = [yr.detach(), a.grad, b.grad] + [p.grad.clone() for p in ad.parameters()]
+    import copy
+    adg = copy.deepcopy(ad).to(device).bfloat16()
+    for p in adg.parameters():
+        p.grad = None
+    ad_, bd_ = f0.to(device).requires_grad_(True), f3.to(device).requires_grad_(True)
+    y = adg.forward_split(ad_, bd_, 8)
+    assert y is not None
+    (y.float() * go.to(device).float()).sum().backward()
+    got = [y.float().cpu(), ad_.grad.float().cpu(), bd_.grad.float().cpu()] + [p.grad.float().cpu() for p in adg.parameters()]
+    for u, v in zip(got, ref):
+        assert u.shape == v.shape and (u - v).abs().max() <= v.abs().max() * 2 ** -5
