@@ -39,7 +39,6 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-constexpr int WPAD = 96;             // padded filter row: taps at [32, 32+K)
 constexpr int WAVES = 4;
 constexpr int LDS_LIMIT = 160 * 1024;
 
@@ -65,43 +64,36 @@ struct Seg {
     static constexpr int STRIDE = lds_stride_bytes(WL);
 };
 
-// Packed filter image (built once per weight version by ppea_dwconv_lk_pack_bf16):
-//   img[c][copy 0..3][ky][WPAD] bf16,  img[..][copy][ky][i] = wpad[ky][i + copy],
-//   wpad[ky][i] = w[ky][i - 32] for 0 <= i - 32 < K, else 0   (dgrad: both filter axes reversed).
-// The B fragment of (ky, chunk s) for lane l is wpad[ky][i0 .. i0+7], i0 = 32 + 32*s + 8*(l>>4) - (l&15)
-// + (P - JOFF); copy (i0 & 3) makes the start 8-byte aligned -> two ds_read_b64.
-constexpr int NCOPY = 4;
-constexpr int packed_elems(int K) { return NCOPY * K * WPAD; }
+// Packed filter image (built once per weight version by ppea_dwconv_lk_pack_bf16): the Toeplitz fragments themselves, in
+// REGISTER layout --
+//   img[c][ky][s][lane][0..7] bf16 = wpad[ky][i0 + j],  i0 = 32 + 32 s + 8 (lane >> 4) - (lane & 15) + (P - JOFF),
+//   wpad[ky][i] = w[ky][i - 32] for 0 <= i - 32 < K, else 0        (dgrad: both filter axes reversed)
+// -- so a wave fetches the B fragment of (ky, chunk s) with ONE coalesced 16-byte load per lane (1 KB per wave
+// instruction).  Round 1 / 2 kept a 4-shifted-copy source image (24 KB per channel) and gathered each fragment with two
+// 8-byte loads per lane at 2-byte-granular offsets: 134 poorly coalesced loads per lane at k = 31, measured at 12 % (stage 0)
+// to 30 % (stage 2) of a wave's time (tools/dwconv_phases.py).  The image is 62 KB per channel at k = 31; the waves of a
+// channel read the same bytes (L2).
+constexpr int frag_ns(int K) { return (16 + 2 * (K / 2) <= 32) ? 1 : 2; }
+constexpr int packed_elems(int K) { return K * frag_ns(K) * 64 * 8; }
 
-template <int K, int P, int JOFF>
+template <int K, int NS>
 __device__ __forceinline__ bf16x8 load_bfrag(const uint16_t* __restrict__ img, int ky, int s, int lane) {
-    const int i0 = 32 + 32 * s + 8 * (lane >> 4) - (lane & 15) + (P - JOFF);
-    const int copy = i0 & 3;
-    const uint2* p = reinterpret_cast<const uint2*>(img + (copy * K + ky) * WPAD + (i0 - copy));
-    const uint2 lo = p[0], hi = p[1];
-    return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + ((ky * NS + s) * 64 + lane) * 8));
 }
 
 __global__ void pack_filter_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int C, int K, int flip) {
-    const long total = (long)C * NCOPY * K * WPAD;
+    const int NS = frag_ns(K), P = K / 2, JOFF = NS == 1 ? 8 : 16;
+    const long total = (long)C * K * NS * 512;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int col = (int)(i % WPAD);
-        const int ky = (int)((i / WPAD) % K);
-        const int copy = (int)((i / ((long)WPAD * K)) % NCOPY);
-        const int c = (int)(i / ((long)WPAD * K * NCOPY));
-        const int t = col + copy - 32;
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const long r = i >> 9;                                   // (c * K + ky) * NS + s
+        const int sidx = (int)(r % NS), ky = (int)((r / NS) % K), c = (int)(r / ((long)NS * K));
+        const int t = 32 * sidx + 8 * (lane >> 4) - (lane & 15) + (P - JOFF) + j;      // tap index = i0 + j - 32
         float v = 0.f;
         if (t >= 0 && t < K)
             v = flip ? w[((long)c * K + (K - 1 - ky)) * K + (K - 1 - t)] : w[((long)c * K + ky) * K + t];
         out[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
     }
-}
-
-// Copy a channel's packed image (16-byte granules) into the wave's LDS region.
-__device__ __forceinline__ void copy_image(uint8_t* dst, const uint16_t* __restrict__ src, int elems, int lane) {
-    const uint4* s4 = reinterpret_cast<const uint4*>(src);
-    uint4* d4 = reinterpret_cast<uint4*>(dst);
-    for (int i = lane; i < elems / 8; i += WAVE) d4[i] = s4[i];
 }
 
 struct Item {
@@ -393,9 +385,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
     constexpr int AGPR_FROM = 6;             // big-filter fragments [AGPR_FROM, K*NS) live in AGPRs
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // One LDS region per wave: first the packed filter image of the wave's channel (needed only while
-    // the Toeplitz fragments are built), then overlaid by the wave's input tile(s).  Nothing is shared
-    // between waves, so the kernel has no workgroup barrier.
+    // One LDS region per wave: the wave's input tile(s).  Nothing is shared between waves, so the kernel has no
+    // workgroup barrier.
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const long wid = (long)blockIdx.x * WAVES + wave;
@@ -407,8 +398,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
 #endif
     PROF_T(t_begin);
     // The Toeplitz fragments come straight from the packed image in global memory (L2: the waves of a channel
-    // read the same 24 KB): 2 x 8 bytes per fragment and lane, all issued before the first wait.  (Staging the
-    // image through LDS first cost 17-32 % of a wave's time.)
+    // read the same bytes), already in register layout: one coalesced 16-byte load per fragment and lane, all
+    // issued before the first wait.
     const uint16_t* wimg_b = w_big + (long)c * packed_elems(K);
     const uint16_t* wimg_s = (KS > 0) ? w_small + (long)c * packed_elems(KS) : nullptr;
 
@@ -417,7 +408,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
 #pragma unroll
     for (int ky = 0; ky < K; ++ky)
 #pragma unroll
-        for (int s = 0; s < GE::NS; ++s) bf_big[ky][s] = load_bfrag<K, GE::P, GE::JOFF>(wimg_b, ky, s, lane);
+        for (int s = 0; s < GE::NS; ++s) bf_big[ky][s] = load_bfrag<K, GE::NS>(wimg_b, ky, s, lane);
     // Park most Toeplitz fragments in the accumulator half of the unified register file (MFMA reads its
     // B operand from AGPRs directly); this keeps the arch VGPRs free for A-fragment prefetch.
 #pragma unroll
@@ -428,7 +419,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     bf16x8 bf_small[(KS > 0 ? KS : 1)][1];
     if constexpr (KS > 0) {
 #pragma unroll
-        for (int ky = 0; ky < KS; ++ky) bf_small[ky][0] = load_bfrag<KS, GS::P, GS::JOFF>(wimg_s, ky, 0, lane);
+        for (int ky = 0; ky < KS; ++ky) bf_small[ky][0] = load_bfrag<KS, GS::NS>(wimg_s, ky, 0, lane);
     }
 
     uint8_t* tile0 = smem + (long)wave * region_bytes;
@@ -575,7 +566,6 @@ int launch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const u
            uint16_t* o1, int N, int C, int H, int W, hipStream_t st, float* stats = nullptr, int* wpc_out = nullptr) {
     constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
     constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
-    constexpr int FILT_BYTES = (packed_elems(K) + (KS > 0 ? packed_elems(KS) : 0)) * 2;
     if ((long)N * C * H * W >= (1L << 31)) return PPEA_ERR_UNSUPPORTED;      // 32-bit element offsets
     if ((long)N * C * H * W < 8) return PPEA_ERR_UNSUPPORTED;                // masked lanes read the first 16 bytes
     // largest band / stacking whose per-wave region fits four times into the 160 KB of LDS
@@ -586,7 +576,7 @@ int launch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const u
         for (; g >= 1; --g) {
             const int rows = (g > 1) ? g * (H + K - 1) : ((H < cand ? H : cand) + K - 1);
             const int tb = (rows * STRIDE_B + 15) & ~15;
-            const int reg = (NT_IN * tb > FILT_BYTES) ? NT_IN * tb : FILT_BYTES;
+            const int reg = NT_IN * tb;
             if (WAVES * reg <= LDS_LIMIT) { band = cand; G = g; tile_bytes = tb; region = reg; break; }
         }
         if (band) break;
