@@ -143,6 +143,10 @@ def main():
     ap.add_argument("--eager", action="store_true", help="no hipGraph: launch every kernel from Python")
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--input_pipeline", action="store_true",
+                    help="also time the device input pipeline (raw uint8 375x1242 KITTI-size frames -> row-P dict: flip, "
+                         "LANCZOS pyramid, ColorJitter; the reference does this on 12 CPU workers per rank) and run the "
+                         "timed steps on its output: adds an `input_pipeline` object (its own img/s) to the line")
     ap.add_argument("--dc", action="store_true",
                     help="Stage-2 decoder adapter (BASELINE config 5: --dc after dc_ft_init, Cityscapes intrinsics; the "
                          "reference trains it at 192x512, BASELINE names 512x1024: pass --height/--width)")
@@ -185,6 +189,31 @@ def main():
     inputs = {k: v.to(device) for k, v in synth.make_inputs(B, H, W, seed=1234 + rank, smooth=True,
                                                             intrinsics="cityscapes" if args.dc else "kitti").items()}
     random.seed(1000 + rank)
+    pipe_info = None
+    if args.input_pipeline:
+        # the batch comes from raw uint8 frames through the device pipeline (bit-exact with the Pillow
+        # arithmetic of the reference's loader); timed on its own, outside the training step's timed region
+        from ppeadepth import input_pipeline as ipl
+        gen = torch.Generator().manual_seed(77 + rank)
+        raw_hw = (375, 1242)
+        base = torch.nn.functional.interpolate(inputs[("color", 0, 0)], raw_hw, mode="bilinear", align_corners=False)
+        raw = {f: (torch.nn.functional.interpolate(inputs[("color", f, 0)], raw_hw, mode="bilinear", align_corners=False)
+                   * 255).round().clamp(0, 255).to(torch.uint8) for f in (0, -1, 1)}
+        del base
+        pipe = ipl.DeviceInputPipeline(raw_hw, H, W, device, K=ipl.KITTI_K)
+        for _ in range(2):
+            out = pipe(raw, generator=gen)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        reps = 5
+        for _ in range(reps):
+            out = pipe(raw, generator=gen)
+        torch.cuda.synchronize()
+        dt_pipe = (time.time() - t0) / reps
+        pipe_info = {"img_per_s": round(B / dt_pipe, 1), "ms_per_batch": round(dt_pipe * 1e3, 2), "raw_hw": list(raw_hw),
+                     "what": "uint8 frame triplets -> flip, 4-level LANCZOS pyramid, ColorJitter per frame and scale, "
+                             "intrinsics (row-P dict); one frame triplet = one img"}
+        inputs = {k: v.contiguous() for k, v in out.items()}
 
     def barrier():
         torch.cuda.synchronize()
@@ -305,6 +334,7 @@ def main():
                        "use_checkpoint": "BN-stat replay, no recompute (288 GB HBM)",
                        "launch": launch},
             "final_loss": round(loss_val, 5),
+            "input_pipeline": pipe_info,
             "sync_bn": ({"launches_per_step": sync_counts.get("launches", 0),
                          "collectives_per_step": sync_counts.get("collectives", 0),
                          "forced_single_rank": bool(pdist.FORCE_COLLECTIVES and world == 1)}

@@ -583,23 +583,36 @@ def test_val_absrel_matches_reference_on_synthetic_eigen_split(device, golden, t
 
 
 def test_device_input_pipeline_feeds_process_batch(device):
-    """SURVEY 8(f)-3 on the GPU: the device pyramid equals the CPU evaluation of the same pipeline byte for byte (which
-    tests/test_host_cpu.py pins to Pillow's LANCZOS), and its row-P dictionary drives `process_batch`."""
+    """SURVEY 8(f)-3 on the GPU against PILLOW ITSELF (the arithmetic the reference's loader runs, mono_dataset.py:88-111,
+    183-190): LANCZOS pyramid chained scale to scale and torchvision's PIL-path ColorJitter (oracle/ref_jitter.py), every
+    byte of `color` and `color_aug` equal; the row-P dictionary then drives `process_batch`."""
+    import numpy as np
+    from PIL import Image
+    from oracle import ref_jitter
     from ppeadepth import input_pipeline as ip
     g = torch.Generator().manual_seed(0)
     Hr, Wr, H, W, B = 96, 320, 64, 96, 2
     raw = {f: torch.randint(0, 256, (B, 3, Hr, Wr), generator=g, dtype=torch.uint8) for f in (0, -1, 1)}
-    flip, aug = torch.tensor([True, False]), torch.tensor([True, False])
-    jit = ip.draw_jitter_params(B, g)
+    flip, aug = torch.tensor([True, False]), torch.tensor([True, True])
+    jit = {(f, s): ip.draw_jitter_params(B, g) for f in (0, -1, 1) for s in range(4)}     # a draw per frame and scale
     out_d = ip.DeviceInputPipeline((Hr, Wr), H, W, device)(raw, aug, flip, jit)
     out_c = ip.DeviceInputPipeline((Hr, Wr), H, W, "cpu")(raw, aug, flip, jit)
+    for f in (0, -1, 1):
+        for b in range(B):
+            im = Image.fromarray(raw[f][b].permute(1, 2, 0).numpy())
+            if bool(flip[b]):
+                im = im.transpose(Image.FLIP_LEFT_RIGHT)
+            for s in range(4):
+                im = im.resize((W // 2 ** s, H // 2 ** s), Image.LANCZOS)
+                p = jit[(f, s)]
+                want_c = np.asarray(im)
+                want_a = ref_jitter.color_jitter(want_c, p["order"][b].tolist(), float(p["brightness"][b]),
+                                                 float(p["contrast"][b]), float(p["saturation"][b]), float(p["hue"][b]))
+                for key, want in ((("color", f, s), want_c), (("color_aug", f, s), want_a)):
+                    got = (out_d[key][b].cpu() * 255.0).round().to(torch.uint8).permute(1, 2, 0).numpy()
+                    assert np.array_equal(got, want), (key, b, int(np.abs(got.astype(int) - want).max()))
     for k, v in out_c.items():
-        if k[0] == "color":
-            # same bytes (the float32 x / 255 itself differs by an ulp between the host and the device divider)
-            assert torch.equal((out_d[k].cpu() * 255).round().to(torch.uint8), (v * 255).round().to(torch.uint8)), k
-            assert torch.allclose(out_d[k].cpu(), v, atol=1e-6)
-        else:
-            assert torch.allclose(out_d[k].cpu(), v, atol=2e-6), k
+        assert torch.allclose(out_d[k].cpu(), v, atol=2e-6), k
     opt, model, tr = _build(device, B, H, W)
     outputs, losses = tr.process_batch(out_d, True)
     assert torch.isfinite(losses["loss"]).item() and outputs[("disp", 0)].shape == (B, 1, H, W)
