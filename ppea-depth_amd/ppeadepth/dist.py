@@ -8,9 +8,10 @@ all-reduce of the trainable gradients (80.3 M fp32 = 321 MB at 31B; 1 306 tensor
 MI355X design: xGMI is point-to-point (7 links x ~153 GB/s per GPU), so few, large collectives win.
 All trainable gradients live in ONE flat fp32 buffer (`FlatGrads`): `p.grad` of every trainable
 parameter is a view into it, autograd accumulates straight into the buffer, zeroing is one
-memset, and the exchange is `n_chunks` all-reduces of ~40-80 MB each, issued on a side stream from
-autograd hooks as soon as backward has produced the last gradient of a chunk (`FlatGrads.install_hooks`;
-parameters are laid out in reverse registration order, i.e. roughly in the order backward finishes them).
+memset, and the exchange is a handful of all-reduces of <= 84 MB each, issued from autograd hooks IN LINE on the
+stream that produced a range's gradients -- and on that stream's own communicator -- as soon as backward has produced
+the last gradient of the range (`FlatGrads.install_hooks`; ranges = branches of the step, laid out in the order
+backward finishes them).
 """
 import os
 
@@ -396,6 +397,18 @@ class TrainEngine:
         call("ppea_adam_flat_f32", ptr(self.P), ptr(self.flat.flat), ptr(self.M), ptr(self.V),
              ptr(self.W16) if self.n_lo else None, self.flat.numel, self.n_lo, ptr(self.adam_state),
              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), stream_ptr())
+
+    # ---- learning-rate schedule --------------------------------------------------------------------------------
+    # Reference: StepLR(optimizer, scheduler_step_size, 0.1) wrapped by `accelerator.prepare` (trainer.py:144, 153) and
+    # stepped once per epoch (trainer.py:418).  Accelerate's AcceleratedScheduler (scheduler.py:69-82, same in the pinned
+    # 0.18.0) steps the wrapped scheduler `num_processes` times per call unless split_batches is set -- so on 8 GPUs the
+    # reference's learning rate drops every ceil(15 / 8) = 2 epochs, not every 15.  PRESERVED by default (a drop-in
+    # replacement must train with the reference's schedule under the same launch); `lr_quirk=False` steps once per call
+    # (the schedule the options describe).
+    def scheduler_step(self, lr_quirk=True):
+        for _ in range(world_size() if lr_quirk else 1):
+            self.scheduler.step()
+        self.sync_lr()
 
     def sync_lr(self):
         """Push the optimizer's (scheduled) learning rate into the device scalar the step kernel reads."""

@@ -494,3 +494,26 @@ def test_device_color_jitter_is_bit_exact_with_the_pillow_path_of_the_reference(
     d1 = (out[("color_aug", -1, 0)] - out[("color", -1, 0)])[0].mean((1, 2))
     assert float(d0.abs().max()) > 1e-3 and float((d0 - d1).abs().max()) > 1e-4      # different draws per frame
     assert torch.equal(out[("color_aug", 1, 0)][1], out[("color", 1, 0)][1])
+
+
+def test_scheduler_step_preserves_accelerates_num_processes_quirk():
+    """SURVEY 8(e): Accelerate's wrapped StepLR steps `num_processes` times per `scheduler.step()` (trainer.py:144, 418;
+    accelerate scheduler.py:69-82), so on 8 GPUs the reference's LR drops every ceil(15 / 8) = 2 epochs.  TrainEngine
+    preserves that by default and offers the un-quirked schedule."""
+    dist_mod = _load_by_path("dist")
+    p = torch.nn.Parameter(torch.zeros(1))
+    for world, quirk, drops_after in ((8, True, 2), (8, False, 15), (1, True, 15)):
+        eng = types.SimpleNamespace(sync_lr=lambda: None)
+        eng.optimizer = torch.optim.Adam([p], 1e-4)
+        eng.scheduler = torch.optim.lr_scheduler.StepLR(eng.optimizer, 15, 0.1)
+        saved = dist_mod.world_size
+        dist_mod.world_size = lambda w=world: w
+        try:
+            epochs = 0
+            while eng.optimizer.param_groups[0]["lr"] > 0.5e-4:
+                eng.optimizer.step()
+                dist_mod.TrainEngine.scheduler_step(eng, lr_quirk=quirk)
+                epochs += 1
+        finally:
+            dist_mod.world_size = saved
+        assert epochs == drops_after, (world, quirk, epochs)
