@@ -65,6 +65,15 @@ int ppea_dwconv_lk_pack_bf16(const float* w, void* packed, int C, int K, int fli
 int ppea_dwconv_lk_fwd_bf16p(const uint16_t* x, const void* packed_big, const void* packed_small,
                              uint16_t* y_big, uint16_t* y_small,
                              int N, int C, int H, int W, int K, int KS, void* stream);
+/* Forward with the BatchNorm (+ ReLU) of the INPUT fused into the staging pass: RepLKBlock's pw1 conv_bn_relu -> large
+ * kernel (replknet_adapter.py:305-308 with :182-197).  x = the 1x1 conv's output, `sums` [C][P][2] its epilogue's partial
+ * (sum, sum of squares) (ppea_pwconv_stats_bf16), count = N*H*W.  Every wave finalises its channel's statistics (fp64, the
+ * arithmetic of ppea_bn_finalize_sums_f32) and stages relu(gamma * (x - mean) * invstd + beta) rounded to bf16, zero
+ * outside the plane; mean / invstd [C] are written for backward, running statistics updated unless NULL.  KS must be 5. */
+int ppea_dwconv_lk_fwd_bn_bf16p(const uint16_t* x, const void* packed_big, const void* packed_small, uint16_t* y_big,
+                                uint16_t* y_small, const float* sums, int P, long count, const float* gamma,
+                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                float* mean, float* invstd, int N, int C, int H, int W, int K, int KS, void* stream);
 /* forward + the statistics of the two BatchNorms that follow the re-parameterised pair (replknet_adapter.py:232-239):
  * stats [2][C][P][2] fp32, P = ppea_dwconv_lk_stats_partials(...) partial (sum, sum of squares) pairs per channel of the
  * stored y_big (first half) / y_small values; reduce each half with ppea_bn_finalize_sums_f32. */

@@ -104,11 +104,34 @@ struct Item {
     int x0;        // first output column of the segment
 };
 
+// Training-mode BatchNorm (+ ReLU) of the conv's INPUT, applied while the planes are staged (forward only): the 1x1
+// conv that produced the input left per-channel partial sums in its epilogue (ppea_pwconv_stats_bf16), every wave
+// finalises its channel's statistics in its prologue (same fp64 arithmetic and order as bn_finalize_sums) and stages
+// relu(a * z + o) -- the conv_bn_relu between pw1 and the large kernel (replknet_adapter.py:305-308, 182-197) costs no
+// launch and no pass over the activation.  Padding stays zero: the reference pads the ACTIVATED tensor.
+struct BnIn {
+    const float* sums;           // [C][P][2] partial (sum, sum of squares); nullptr: no BatchNorm
+    int P;
+    float count, eps, momentum;
+    const float *gamma, *beta;
+    float *running_mean, *running_var, *mean_out, *invstd_out;
+};
+
+__device__ __forceinline__ uint32_t bnrelu2(uint32_t v, float a, float o) {
+    const float lo = fmaxf(a * __uint_as_float(v << 16) + o, 0.f), hi = fmaxf(a * __uint_as_float(v & 0xffff0000u) + o, 0.f);
+    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)lo) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)hi) << 16);
+}
+template <bool BN>
+__device__ __forceinline__ uint4 bn_piece(uint4 v, float a, float o) {
+    if constexpr (BN) return make_uint4(bnrelu2(v.x, a, o), bnrelu2(v.y, a, o), bnrelu2(v.z, a, o), bnrelu2(v.w, a, o));
+    else return v;
+}
+
 // Stage G planes' rows [y0 - P, y0 + rows + P) x cols [x0 - JOFF, x0 - JOFF + WL) into LDS (bf16, zeros
 // outside).  Lane -> (row within a block of 64/CG rows, 16-byte column group); no divisions in the loop.
-template <int K, int NSEG>
+template <int K, int NSEG, bool BN = false>
 __device__ __forceinline__ void stage_planes(uint8_t* tile, const uint16_t* __restrict__ src, const Item& it,
-                                             int C, int c, int H, int W, int lane) {
+                                             int C, int c, int H, int W, int lane, float bn_a = 1.f, float bn_o = 0.f) {
     using GE = Geo<K>;
     constexpr int CG = Seg<K, NSEG>::WL / 8;                   // 16-byte groups per staged row
     constexpr int RPI = 64 / CG;                               // rows per wave iteration
@@ -139,8 +162,8 @@ __device__ __forceinline__ void stage_planes(uint8_t* tile, const uint16_t* __re
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (rb + u * RPI < rows_l) {
-                    const uint4 w = make_uint4(ok[u] ? v[u].x : 0u, ok[u] ? v[u].y : 0u, ok[u] ? v[u].z : 0u,
-                                               ok[u] ? v[u].w : 0u);
+                    const uint4 t = bn_piece<BN>(v[u], bn_a, bn_o);
+                    const uint4 w = make_uint4(ok[u] ? t.x : 0u, ok[u] ? t.y : 0u, ok[u] ? t.z : 0u, ok[u] ? t.w : 0u);
                     *reinterpret_cast<uint4*>(dst0 + (long)(rb - r_in + u * RPI) * STRIDE_B) = w;
                 }
             }
@@ -158,6 +181,16 @@ __device__ __forceinline__ void stage_planes(uint8_t* tile, const uint16_t* __re
                 uint4 v;
                 v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
                 v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+                if constexpr (BN) {                              // columns outside the image stay zero (padding)
+                    const uint4 t = bn_piece<true>(v, bn_a, bn_o);
+                    const bool i0 = gx >= 0 && gx < W, i1 = gx + 1 >= 0 && gx + 1 < W, i2 = gx + 2 >= 0 && gx + 2 < W,
+                               i3 = gx + 3 >= 0 && gx + 3 < W, i4 = gx + 4 >= 0 && gx + 4 < W, i5 = gx + 5 >= 0 && gx + 5 < W,
+                               i6 = gx + 6 >= 0 && gx + 6 < W, i7 = gx + 7 >= 0 && gx + 7 < W;
+                    v.x = (i0 ? t.x & 0xffffu : 0u) | (i1 ? t.x & 0xffff0000u : 0u);
+                    v.y = (i2 ? t.y & 0xffffu : 0u) | (i3 ? t.y & 0xffff0000u : 0u);
+                    v.z = (i4 ? t.z & 0xffffu : 0u) | (i5 ? t.z & 0xffff0000u : 0u);
+                    v.w = (i6 ? t.w & 0xffffu : 0u) | (i7 ? t.w & 0xffff0000u : 0u);
+                }
                 *reinterpret_cast<uint4*>(dst) = v;
             }
         }
@@ -200,9 +233,9 @@ __device__ __forceinline__ void stage_load(uint4 (&v)[SU], const uint16_t* __res
     }
 }
 
-template <int K, int NSEG>
+template <int K, int NSEG, bool BN = false>
 __device__ __forceinline__ void stage_store(const uint4 (&v)[SU], uint8_t* tile, const Item& it, int H, int W,
-                                            int lane) {
+                                            int lane, float bn_a = 1.f, float bn_o = 0.f) {
     using GE = Geo<K>;
     constexpr int CG = Seg<K, NSEG>::WL / 8, RPI = 64 / CG;
     constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
@@ -217,8 +250,8 @@ __device__ __forceinline__ void stage_store(const uint4 (&v)[SU], uint8_t* tile,
     for (int u = 0; u < SU; ++u) {
         const int gy = lo + j * RPI + r_in;
         if (r_in < RPI && g < it.G && gy < hi) {
-            const uint4 w = make_uint4(col_ok ? v[u].x : 0u, col_ok ? v[u].y : 0u, col_ok ? v[u].z : 0u,
-                                       col_ok ? v[u].w : 0u);
+            const uint4 t = bn_piece<BN>(v[u], bn_a, bn_o);
+            const uint4 w = make_uint4(col_ok ? t.x : 0u, col_ok ? t.y : 0u, col_ok ? t.z : 0u, col_ok ? t.w : 0u);
             *reinterpret_cast<uint4*>(tile + ((long)g * rows_l + (gy - (it.y0 - GE::P))) * STRIDE_B + cg * 16) = w;
         }
         if (++j == ppv) { j = 0; ++g; }
@@ -373,12 +406,13 @@ __device__ __forceinline__ void tile_stats(const f32x4& acc, const RowOffs& ro, 
 
 // MODE 0: fwd  (in0 = x; out0 = y_big, out1 = y_small if KS)
 // MODE 1: dgrad (in0 = dy_big, in1 = dy_small if KS; out0 = dx), filters flipped
-template <int K, int KS, int MODE, int NSEG>
+template <int K, int KS, int MODE, int NSEG, bool BN = false>
 __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     const uint16_t* __restrict__ in0, const uint16_t* __restrict__ in1, const uint16_t* __restrict__ w_big,
     const uint16_t* __restrict__ w_small, uint16_t* __restrict__ out0, uint16_t* __restrict__ out1, int N, int C,
     int H, int W, int G, int band, int bands, int segs, int items_per_channel, int ipw, int wpc,
-    long total_waves, int tile_bytes, int region_bytes, float* __restrict__ stats) {
+    long total_waves, int tile_bytes, int region_bytes, float* __restrict__ stats, BnIn bn) {
+    static_assert(!BN || MODE == 0, "the fused input BatchNorm is a forward feature");
     using GE = Geo<K>;
     using GS = Geo<(KS > 0 ? KS : 5)>;
     constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
@@ -420,6 +454,34 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     if constexpr (KS > 0) {
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) bf_small[ky][0] = load_bfrag<KS, GS::NS>(wimg_s, ky, 0, lane);
+    }
+
+    // fused input BatchNorm: this channel's statistics from the producer's partial sums (bn_finalize_sums' arithmetic)
+    float bn_a = 1.f, bn_o = 0.f;
+    if constexpr (BN) {
+        const float2* sp = reinterpret_cast<const float2*>(bn.sums) + (long)c * bn.P;
+        double ds = 0.0, dq = 0.0;
+        for (int i = lane; i < bn.P; i += 64) {
+            const float2 v = sp[i];
+            ds += (double)v.x; dq += (double)v.y;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, WAVE); dq += __shfl_xor(dq, o, WAVE); }
+        const double mean = ds / (double)bn.count;
+        double var = dq / (double)bn.count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float invstd = rsqrtf((float)var + bn.eps);
+        bn_a = bn.gamma[c] * invstd;
+        bn_o = bn.beta[c] - (float)mean * bn_a;
+        if (lane == 0 && wid == (long)c * wpc) {                 // one writer per channel
+            bn.mean_out[c] = (float)mean;
+            bn.invstd_out[c] = invstd;
+            if (bn.running_mean != nullptr) {
+                const float unbiased = (float)(var * (double)bn.count / fmax((double)bn.count - 1.0, 1.0));
+                bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * (float)mean;
+                bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * unbiased;
+            }
+        }
     }
 
     uint8_t* tile0 = smem + (long)wave * region_bytes;
@@ -469,7 +531,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
         Item nxt;
         const bool have_next = make_item(first_item + (++done), nxt);
         if (fast) {
-            stage_store<K, NSEG>(pre, tile0, it, H, W, lane);
+            stage_store<K, NSEG, BN>(pre, tile0, it, H, W, lane, bn_a, bn_o);
             if constexpr (NT_IN == 2) {
                 uint4 second[SU];
                 stage_load<K, NSEG>(second, in1, it, C, c, H, W, lane);
@@ -477,7 +539,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
             }
             if (have_next) stage_load<K, NSEG>(pre, in0, nxt, C, c, H, W, lane);   // lands during the MFMAs below
         } else {
-            stage_planes<K, NSEG>(tile0, in0, it, C, c, H, W, lane);
+            stage_planes<K, NSEG, BN>(tile0, in0, it, C, c, H, W, lane, bn_a, bn_o);
             if constexpr (NT_IN == 2) stage_planes<K, NSEG>(tile1, in1, it, C, c, H, W, lane);
         }
         asm volatile("" ::: "memory");      // compiler fence: staging stores stay above the asm LDS reads
@@ -561,9 +623,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
 
 // stats / wpc_out: forward only -- per-wave partial sums for the BatchNorm pair (see the kernel); wpc_out != nullptr:
 // do not launch, return the number of waves per channel (= partials per channel) the launch would use
-template <int K, int KS, int MODE, int NSEG>
+template <int K, int KS, int MODE, int NSEG, bool BN = false>
 int launch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0,
-           uint16_t* o1, int N, int C, int H, int W, hipStream_t st, float* stats = nullptr, int* wpc_out = nullptr) {
+           uint16_t* o1, int N, int C, int H, int W, hipStream_t st, float* stats = nullptr, int* wpc_out = nullptr,
+           const BnIn* bn = nullptr) {
     constexpr int STRIDE_B = Seg<K, NSEG>::STRIDE;
     constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
     if ((long)N * C * H * W >= (1L << 31)) return PPEA_ERR_UNSUPPORTED;      // 32-bit element offsets
@@ -596,7 +659,8 @@ int launch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const u
     if (wpc_out != nullptr) { *wpc_out = wpc; return 0; }
     const long total_waves = (long)C * wpc;
     const size_t lds = (size_t)WAVES * region;
-    auto kern = dwconv_mfma_kernel<K, KS, MODE, NSEG>;
+    auto kern = dwconv_mfma_kernel<K, KS, MODE, NSEG, BN>;
+    const BnIn bnv = bn != nullptr ? *bn : BnIn{nullptr, 0, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
@@ -604,7 +668,7 @@ int launch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const u
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((total_waves + WAVES - 1) / WAVES)), dim3(64 * WAVES), lds, st, in0,
                        in1, wb, ws, o0, o1, N, C, H, W, G, band, bands, segs, items_per_channel, ipw, wpc,
-                       total_waves, tile_bytes, region, stats);
+                       total_waves, tile_bytes, region, stats, bnv);
     return launch_status();
 }
 
@@ -617,21 +681,30 @@ inline long staged_cols(int W, int nseg) {
 
 template <int K, int KS, int MODE>
 int launch_k(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0,
-             uint16_t* o1, int N, int C, int H, int W, hipStream_t st, float* stats, int* wpc_out) {
+             uint16_t* o1, int N, int C, int H, int W, hipStream_t st, float* stats, int* wpc_out, const BnIn* bn) {
     const long c5 = staged_cols<K>(W, 5), c3 = staged_cols<K>(W, 3), c2 = staged_cols<K>(W, 2);
-    if (c5 <= c3 && c5 <= c2) return launch<K, KS, MODE, 5>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out);
-    if (c3 <= c2) return launch<K, KS, MODE, 3>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out);
+    const int nseg = (c5 <= c3 && c5 <= c2) ? 5 : (c3 <= c2 ? 3 : 2);
+    if constexpr (MODE == 0 && KS == 5) {
+        if (bn != nullptr) {                                     // fused input BatchNorm + ReLU (RepLKBlock forward)
+            if (nseg == 5) return launch<K, KS, MODE, 5, true>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out, bn);
+            if (nseg == 3) return launch<K, KS, MODE, 3, true>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out, bn);
+            return launch<K, KS, MODE, 2, true>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out, bn);
+        }
+    }
+    if (bn != nullptr) return PPEA_ERR_UNSUPPORTED;
+    if (nseg == 5) return launch<K, KS, MODE, 5>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out);
+    if (nseg == 3) return launch<K, KS, MODE, 3>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out);
     return launch<K, KS, MODE, 2>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out);
 }
 
 template <int MODE>
 int dispatch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0,
              uint16_t* o1, int N, int C, int H, int W, int K, int KS, hipStream_t st, float* stats = nullptr,
-             int* wpc_out = nullptr) {
+             int* wpc_out = nullptr, const BnIn* bn = nullptr) {
 #define PPEA_CASE(K_)                                                                             \
     case K_:                                                                                      \
-        return KS == 5 ? launch_k<K_, 5, MODE>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out)   \
-                       : launch_k<K_, 0, MODE>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out);
+        return KS == 5 ? launch_k<K_, 5, MODE>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out, bn)   \
+                       : launch_k<K_, 0, MODE>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out, bn);
     switch (K) {
         PPEA_CASE(31) PPEA_CASE(29) PPEA_CASE(27) PPEA_CASE(13)
         default: return PPEA_ERR_UNSUPPORTED;
@@ -690,6 +763,24 @@ int ppea_dwconv_lk_fwd_stats_bf16p(const uint16_t* x, const void* packed_big, co
     if (KS != 0 && KS != 5) return PPEA_ERR_UNSUPPORTED;
     return dispatch<0>(x, nullptr, (const uint16_t*)packed_big, (const uint16_t*)packed_small, y_big, y_small, N, C,
                        H, W, K, KS, (hipStream_t)stream, stats, nullptr);
+}
+
+// Forward with the BatchNorm (+ ReLU) of the INPUT fused into the staging pass (RepLKBlock: pw1 conv_bn_relu -> large
+// kernel, replknet_adapter.py:305-308): x = the 1x1 conv's output, `sums` [C][P][2] its epilogue's partial (sum, sum of
+// squares) (ppea_pwconv_stats_bf16), count = N*H*W.  Every wave finalises its channel (fp64, the arithmetic of
+// ppea_bn_finalize_sums_f32), stages relu(gamma * (x - mean) * invstd + beta) rounded to bf16 (zero padding outside the
+// plane), and the channel's first wave writes mean / invstd [C] (saved for backward) and updates the running statistics
+// (NULL: no update).  KS must be 5.
+int ppea_dwconv_lk_fwd_bn_bf16p(const uint16_t* x, const void* packed_big, const void* packed_small, uint16_t* y_big,
+                                uint16_t* y_small, const float* sums, int P, long count, const float* gamma,
+                                const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                float* mean, float* invstd, int N, int C, int H, int W, int K, int KS, void* stream) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || KS != 5 || packed_small == nullptr || y_small == nullptr) return PPEA_ERR_UNSUPPORTED;
+    if (sums == nullptr || P <= 0 || count <= 0 || gamma == nullptr || beta == nullptr || mean == nullptr || invstd == nullptr)
+        return PPEA_ERR_ARG;
+    const BnIn bn{sums, P, (float)count, eps, momentum, gamma, beta, running_mean, running_var, mean, invstd};
+    return dispatch<0>(x, nullptr, (const uint16_t*)packed_big, (const uint16_t*)packed_small, y_big, y_small, N, C,
+                       H, W, K, KS, (hipStream_t)stream, nullptr, nullptr, &bn);
 }
 
 int ppea_dwconv_lk_bwd_data_bf16p(const uint16_t* dy_big, const uint16_t* dy_small, const void* packed_big_flip,

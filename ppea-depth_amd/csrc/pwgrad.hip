@@ -12,6 +12,7 @@
 //     by a second tiny kernel: deterministic, and no cross-XCD atomics;
 //   * the row sums (bias gradients) ride along in the n-tile-0 workgroups.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -128,6 +129,146 @@ __global__ __launch_bounds__(256) void pwgrad_kernel(const uint16_t* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v2: the same contraction with a three-stage LDS ring filled by LDS-DMA (`global_load_lds`, 16 bytes per lane), counted
+// `s_waitcnt vmcnt(N)` + ONE raw `s_barrier` per step (two steps in flight across it) -- the pipeline of pwconv v2
+// (pwconv.hip).  Both operand tiles are [128 rows][BK pixels] row-major images read with `ds_read_b128`; LDS-DMA writes
+// wave-uniform base + lane * 16, so the bank swizzle sits on the SOURCE address: slot s of row r holds pixel chunk
+// s ^ ((r >> 1) & 7) (128-byte rows) / s ^ (2 ((r >> 2) & 1)) (64-byte rows).  The MFMA operands are swapped (the
+// accumulator holds the transposed tile): a lane owns 4 consecutive columns n of one row m = one 16-byte slab store.
+// Requirement: HW % BK == 0 (a step never straddles two images); other shapes stay on v1.
+constexpr int NSTAGE2 = 3;
+
+template <int BK> __device__ __forceinline__ int g_swz16(int row) { return BK == 64 ? ((row >> 1) & 7) : (2 * ((row >> 2) & 1)); }
+
+template <int BK>
+__global__ __launch_bounds__(256) void pwgrad2_kernel(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q,
+                                                      float* __restrict__ ws, int M, int N, int HW, int spi,
+                                                      int total_steps, int sps, int want_rowsum) {
+    constexpr int RB = BK * 2;                          // bytes per tile row
+    constexpr int TILE = TM * RB, STAGE = 2 * TILE;
+    constexpr int INS = TILE / 1024 / 4;                // LDS-DMA instructions per wave, operand and stage
+    constexpr int LPS = 2 * INS, KH = BK / 32;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int split = blockIdx.x, m0 = blockIdx.y * TM, n0 = blockIdx.z * TN;
+    const int s_begin = split * sps, s_end = min(s_begin + sps, total_steps);
+
+    // per-lane source pointers inside image 0 (advanced per step by a wave-uniform offset)
+    const uint16_t* p_src[INS];
+    const uint16_t* q_src[INS];
+#pragma unroll
+    for (int c = 0; c < INS; ++c) {
+        const int t = c * 4 + wave;
+        const int row = t * (1024 / RB) + lane / (RB / 16), slot = lane % (RB / 16);
+        const int chunk = slot ^ g_swz16<BK>(row);
+        p_src[c] = P + (long)min(m0 + row, M - 1) * HW + 8 * chunk;          // rows past M / N: any valid row (not stored)
+        q_src[c] = Q + (long)min(n0 + row, N - 1) * HW + 8 * chunk;
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)lds;
+    auto glds16 = [&](const uint16_t* src, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    };
+    auto issue = [&](int step, int stage) {
+        const int b = step / spi, p0 = (step - b * spi) * BK;
+        const long po = (long)b * M * HW + p0, qo = (long)b * N * HW + p0;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE + wave * 1024);
+#pragma unroll
+        for (int c = 0; c < INS; ++c) glds16(p_src[c] + po, base + c * 4096);
+#pragma unroll
+        for (int c = 0; c < INS; ++c) glds16(q_src[c] + qo, base + TILE + c * 4096);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, li = lane & 15;
+    int a_off[4][KH], b_off[4][KH];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < KH; ++h) {
+            const int ra = wm * 64 + 16 * i + li, rb = wn * 64 + 16 * i + li;
+            a_off[i][h] = ra * RB + 16 * ((4 * h + g) ^ g_swz16<BK>(ra));
+            b_off[i][h] = TILE + rb * RB + 16 * ((4 * h + g) ^ g_swz16<BK>(rb));
+        }
+    const bool do_rs = want_rowsum && blockIdx.z == 0 && wn == 0;
+
+    const int nsteps = s_end - s_begin;
+    if (nsteps > 0) issue(s_begin, 0);
+    if (nsteps > 1) issue(s_begin + 1, 1);
+    int cur = 0;
+    for (int k = 0; k < nsteps; ++k) {
+        if (k + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (k + 2 < nsteps) issue(s_begin + k + 2, cur >= 1 ? cur - 1 : NSTAGE2 - 1);
+        const uint8_t* buf = lds + cur * STAGE;
+#pragma unroll
+        for (int h = 0; h < KH; ++h) {
+            uint4 au[4], bu[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) au[i] = *reinterpret_cast<const uint4*>(buf + a_off[i][h]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bu[j] = *reinterpret_cast<const uint4*>(buf + b_off[j][h]);
+            if (do_rs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    rs[i] += (bf_lo(au[i].x) + bf_hi(au[i].x)) + (bf_lo(au[i].y) + bf_hi(au[i].y)) +
+                             (bf_lo(au[i].z) + bf_hi(au[i].z)) + (bf_lo(au[i].w) + bf_hi(au[i].w));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bu[j]),
+                                                                        __builtin_bit_cast(bf16x8, au[i]), acc[i][j],
+                                                                        0, 0, 0);
+        }
+        cur = cur == NSTAGE2 - 1 ? 0 : cur + 1;
+    }
+
+    // transposed C layout: col = lane & 15 = row m of the result, rows 4 g + r = 4 consecutive columns n
+    float* out = ws + (long)split * ((long)M * N + M);
+    const bool vec = (N & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + 16 * i + li;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + 16 * j + 4 * g;
+            if (n >= N) continue;
+            float* o = out + (long)m * N + n;
+            if (vec) {                                           // n % 4 == 0 and N % 4 == 0: all four inside, 16-byte aligned
+                *reinterpret_cast<float4*>(o) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < N) o[r] = acc[i][j][r];
+            }
+        }
+    }
+    if (do_rs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = rs[i];
+            v += __shfl_xor(v, 16, WAVE);
+            v += __shfl_xor(v, 32, WAVE);
+            const int m = m0 + wm * 64 + 16 * i + li;
+            if (g == 0 && m < M) out[(long)M * N + m] = v;
+        }
+    }
+}
+
 // out[i] = sum_s ws[s * pitch + i], i < len.  Block = 32 columns x 8 split groups, combined through LDS.
 __global__ __launch_bounds__(256) void pwgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                             long len, long pitch, int S) {
@@ -185,15 +326,43 @@ __global__ __launch_bounds__(256) void pwgrad_reduce_ex_kernel(const float* __re
     }
 }
 
+// v2 (LDS-DMA ring) serves planes whose size is a multiple of its 32-pixel step; PPEA_PWGRAD_V2=0: v1 everywhere
+int pwgrad_bk(int HW) {
+    const char* e = getenv("PPEA_PWGRAD_V2");
+    if (e != nullptr && e[0] == '0') return 0;
+    return (HW % 32) == 0 ? 32 : 0;
+}
+
 void plan(int B, int M, int N, int HW, int& spi, int& total, int& sps, int& S) {
-    spi = (HW + TK - 1) / TK;
+    const int bk = pwgrad_bk(HW);
+    const int tk = bk ? bk : TK;
+    spi = (HW + tk - 1) / tk;
     total = B * spi;
     const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-    int want = (384 + tiles - 1) / tiles;
-    if (want > (total + 3) / 4) want = (total + 3) / 4;      // at least ~4 steps per work item
+    // enough work items to fill the chip once, but every split writes (and the reduce kernel re-reads) a full fp32 copy
+    // of the result: v2's deeper pipeline needs fewer, longer items
+    int want = ((bk ? 288 : 384) + tiles - 1) / tiles;
+    const int min_steps = bk ? 8 : 4;
+    if (want > (total + min_steps - 1) / min_steps) want = (total + min_steps - 1) / min_steps;
     if (want < 1) want = 1;
     sps = (total + want - 1) / want;
     S = (total + sps - 1) / sps;
+}
+
+int launch_main(const void* P, const void* Q, void* workspace, int B, int M, int N, int HW, int want_rowsum, hipStream_t st) {
+    int spi, total, sps, S;
+    plan(B, M, N, HW, spi, total, sps, S);
+    dim3 grid(S, (M + TM - 1) / TM, (N + TN - 1) / TN);
+    if (grid.y > 65535 || grid.z > 65535) return PPEA_ERR_UNSUPPORTED;
+    if (pwgrad_bk(HW) == 32) {
+        constexpr int smem = NSTAGE2 * 2 * TM * 64;
+        hipLaunchKernelGGL(pwgrad2_kernel<32>, grid, dim3(256), smem, st, (const uint16_t*)P, (const uint16_t*)Q,
+                           (float*)workspace, M, N, HW, spi, total, sps, want_rowsum);
+    } else {
+        hipLaunchKernelGGL(pwgrad_kernel, grid, dim3(256), 0, st, (const uint16_t*)P, (const uint16_t*)Q,
+                           (float*)workspace, M, N, HW, spi, total, sps, want_rowsum);
+    }
+    return launch_status();
 }
 
 }  // namespace
@@ -215,10 +384,8 @@ int ppea_pwgrad_bf16(const void* P, const void* Q, float* out, void* workspace, 
     int spi, total, sps, S;
     plan(B, M, N, HW, spi, total, sps, S);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(S, (M + TM - 1) / TM, (N + TN - 1) / TN);
-    if (grid.y > 65535 || grid.z > 65535) return PPEA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(pwgrad_kernel, grid, dim3(256), 0, st, (const uint16_t*)P, (const uint16_t*)Q,
-                       (float*)workspace, M, N, HW, spi, total, sps, want_rowsum);
+    const int err = launch_main(P, Q, workspace, B, M, N, HW, want_rowsum, st);
+    if (err != 0) return err;
     const long len = (long)M * N + (want_rowsum ? M : 0), pitch = (long)M * N + M;
     hipLaunchKernelGGL(pwgrad_reduce_kernel, dim3((unsigned)((len + 31) / 32)), dim3(256), 0, st,
                        (const float*)workspace, out, len, pitch, S);
@@ -234,10 +401,8 @@ int ppea_pwgrad_ex_bf16(const void* P, const void* Q, void* workspace, int B, in
     int spi, total, sps, S;
     plan(B, M, N, HW, spi, total, sps, S);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(S, (M + TM - 1) / TM, (N + TN - 1) / TN);
-    if (grid.y > 65535 || grid.z > 65535) return PPEA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(pwgrad_kernel, grid, dim3(256), 0, st, (const uint16_t*)P, (const uint16_t*)Q,
-                       (float*)workspace, M, N, HW, spi, total, sps, out_b != nullptr ? 1 : 0);
+    const int err = launch_main(P, Q, workspace, B, M, N, HW, out_b != nullptr ? 1 : 0, st);
+    if (err != 0) return err;
     const long pitch = (long)M * N + M;
     const long len = out_b != nullptr ? pitch : (long)M * N;
     hipLaunchKernelGGL(pwgrad_reduce_ex_kernel, dim3((unsigned)((len + 31) / 32)), dim3(256), 0, st,

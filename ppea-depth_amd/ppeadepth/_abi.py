@@ -32,6 +32,7 @@ SIGNATURES = {
     "ppea_dwconv_lk_pack_bf16": [_vp, _vp, _i, _i, _i, _vp],
     "ppea_dwconv_lk_fwd_bf16p": [_vp] * 5 + [_i] * 6 + [_vp],
     "ppea_dwconv_lk_bwd_data_bf16p": [_vp] * 5 + [_i] * 6 + [_vp],
+    "ppea_dwconv_lk_fwd_bn_bf16p": [_vp] * 6 + [_i, _l, _vp, _vp, _f, _f] + [_vp] * 4 + [_i] * 6 + [_vp],
     "ppea_pwconv_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_pwconv_ex_bf16": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ppea_pwgrad_workspace_bytes": [_i, _i, _i, _i],

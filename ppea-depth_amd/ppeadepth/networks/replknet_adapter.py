@@ -160,12 +160,12 @@ class PointwiseConv(nn.Conv2d):
                 return y
         return super().forward(x)
 
-    def forward_sums(self, x):
+    def forward_sums(self, x, always=False):
         """-> (conv(x), sums or None): on the MFMA path, for activations whose BatchNorm takes separate statistics and
-        apply launches (N * HW > 16 384: stages 0 / 1), the GEMM's epilogue also returns the per-channel partial sums
-        that BatchNorm needs (`fused_bn_act(..., sums=sums)`)."""
+        apply launches (N * HW > 16 384: stages 0 / 1; `always`: any size), the GEMM's epilogue also returns the per-channel
+        partial sums that BatchNorm needs (`fused_bn_act(..., sums=sums)`)."""
         if (PW_MFMA and BN_SUMS and x.is_cuda and x.dtype == torch.bfloat16 and not self.weight.requires_grad
-                and x.shape[0] * x.shape[2] * x.shape[3] > 16384):
+                and (always or x.shape[0] * x.shape[2] * x.shape[3] > 16384)):
             r = ops.pwconv_frozen(x, self.weight, want_sums=True)
             if r is not None:
                 return r
@@ -176,6 +176,8 @@ PW_MFMA = True
 # ... and from the large-kernel depthwise conv's epilogue: measured neutral for the step, but the 16 conversions + FMAs per
 # tile sit in the hand-pipelined kernel's instruction stream (31x31 forward 74 -> 82 us), so it is opt-in (PPEA_DW_SUMS=1)
 DW_SUMS = os.environ.get("PPEA_DW_SUMS", "0") == "1"
+# the BatchNorm + ReLU between pw1 and the large kernel applied in the depthwise kernel's staging pass (one rank)
+DW_BN_FUSE = os.environ.get("PPEA_DW_BN", "1") == "1"
 BN_SUMS = os.environ.get("PPEA_BN_SUMS", "1") == "1"   # BatchNorm statistics from the 1x1 conv's epilogue (stages 0 / 1)
 ADAPTER_MFMA = True    # adapters (forward + every gradient) on the NCHW MFMA kernels under bf16
 
@@ -445,6 +447,34 @@ class RepLKBlock(nn.Module):
 
     pre_bn = property(lambda self: self.prelkb_bn)
 
+    def _pw1_large_kernel_fused(self, out):
+        """relu(BN(DW_k(t)) + BN(DW_5(t))) with t = relu(BN(pw1(out))) applied inside the depthwise kernel's staging pass:
+        pw1's GEMM leaves the statistics' partial sums, the depthwise kernel finalises and applies them -- the conv_bn_relu
+        between the two (rka.py:305-308) costs no launch and no pass over the activation.  One rank, bf16 step; else None."""
+        from .. import batchnorm as bnm
+        lk = self.large_kernel
+        big, small = lk.lkb_origin.conv, lk.small_conv.conv
+        conv, bn = self.pw1.conv, self.pw1.bn
+        if not (DW_BN_FUSE and isinstance(conv, PointwiseConv) and isinstance(big, LargeKernelDW) and bn.training
+                and not (bn.sync and bnm._collectives_on()) and bn.running_mean.dtype == torch.float32
+                and not big.weight.requires_grad and not small.weight.requires_grad and small.kernel_size[0] == 5
+                and out.dtype == torch.bfloat16 and out.is_cuda):
+            return None
+        if not ops.dwconv_lk_bn_supported((out.shape[0], conv.out_channels, out.shape[2], out.shape[3]), big.kernel_size[0], 5):
+            return None
+        z1, sums = conv.forward_sums(out, always=True)
+        if sums is None:                                       # this 1x1 conv is not served by the MFMA GEMM: unfused
+            return lk.forward_act(fused_bn_act(z1, bn, act=ops.ACT_RELU), ops.ACT_RELU)
+        y_big, y_small, st = ops.dwconv_lk_bn(z1, sums, bn, big.weight, small.weight)
+        cnt = float(z1.numel() // z1.shape[1])
+        if bnm._ACTIVE_DEFERRED is None:
+            bn.num_batches_tracked += 1
+        else:
+            bnm._ACTIVE_DEFERRED.count(bn)
+            if bn.replay_update and torch.is_grad_enabled():
+                bnm._ACTIVE_DEFERRED.add(bn, st[0], st[1], cnt)
+        return fused_bn_act(y_big, lk.lkb_origin.bn, y_small, lk.small_conv.bn, act=ops.ACT_RELU)
+
     def forward(self, x, pre_out=None, next_bn=None):
         """pre_out / next_bn: see ConvFFN.forward."""
         if FUSE_BN and self.training and x.is_cuda and hasattr(self.large_kernel, "small_conv"):
@@ -458,7 +488,9 @@ class RepLKBlock(nn.Module):
                     adpt, join = _forked_adapter(self.adapter, out)
                 else:
                     adpt = self.adapter(out)
-            t = self.large_kernel.forward_act(self.pw1(out), ops.ACT_RELU)
+            t = self._pw1_large_kernel_fused(out)
+            if t is None:
+                t = self.large_kernel.forward_act(self.pw1(out), ops.ACT_RELU)
             z, s2 = _conv_sums(self.pw2.conv, t)
             if join is not None:
                 join()

@@ -169,6 +169,85 @@ class _DwConvLK(torch.autograd.Function):
         return dx, dwb, dws, None
 
 
+class _DwConvLKBn(torch.autograd.Function):
+    """(DW_k(t), DW_5(t)) with t = relu(BN(z)) never materialised: the BatchNorm of RepLKBlock's pw1 (training mode,
+    statistics from the producing 1x1 conv's epilogue `sums`) and its ReLU are applied while the depthwise kernel stages its
+    planes (csrc/dwconv_mfma.hip, BnIn).  Backward: depthwise data gradient, then the BatchNorm + ReLU backward kernels on
+    the saved pre-BN tensor (relu' is recomputed from it).   networks/replknet_adapter.py:305-308, 182-197, 232-239"""
+
+    @staticmethod
+    def forward(ctx, z, sums, gamma, beta, rm, rv, eps, momentum, w_big, w_small):
+        z = z.contiguous()
+        N, C, H, W = z.shape
+        K = w_big.shape[-1]
+        pb, ps = _packed_filter(w_big, False), _packed_filter(w_small, False)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        st = torch.empty(2, C, device=z.device, dtype=_F32)                     # mean | invstd
+        y_big, y_small = torch.empty_like(z), torch.empty_like(z)
+        _timed("fwd31", K, lambda: call(
+            "ppea_dwconv_lk_fwd_bn_bf16p", ptr(z), ptr(pb), ptr(ps), ptr(y_big), ptr(y_small), ptr(sums, _F32), sums.shape[1],
+            N * H * W, ptr(g), ptr(b), float(eps), float(momentum), ptr(rm), ptr(rv), ptr(st[0]), ptr(st[1]), N, C, H, W, K, 5,
+            stream_ptr()))
+        ctx.save_for_backward(z, st, g, b)
+        ctx.packed = (w_big, w_small)
+        ctx.pdt = (gamma.dtype, beta.dtype)
+        ctx.mark_non_differentiable(st)
+        ctx.set_materialize_grads(False)
+        return y_big, y_small, st
+
+    @staticmethod
+    def backward(ctx, dy_big, dy_small, _dst):
+        z, st, g, b = ctx.saved_tensors
+        N, C, H, W = z.shape
+        K = ctx.packed[0].shape[-1]
+        dy_big = torch.zeros_like(z) if dy_big is None else dy_big.contiguous().to(z.dtype)
+        dy_small = torch.zeros_like(z) if dy_small is None else dy_small.contiguous().to(z.dtype)
+        dt = torch.empty_like(z)
+        pb, ps = _packed_filter(ctx.packed[0], True), _packed_filter(ctx.packed[1], True)
+        _timed("bwd31", K, lambda: call("ppea_dwconv_lk_bwd_data_bf16p", ptr(dy_big), ptr(dy_small), ptr(pb), ptr(ps),
+                                        ptr(dt), N, C, H, W, K, 5, stream_ptr()))
+        # BatchNorm + ReLU backward on the saved pre-BN tensor (as _BnActChannel / _BnAct would)
+        HW = H * W
+        stats = _stats_array((st[0], st[1], g, b, None, None, None, None))
+        sums = torch.empty(3, C, device=z.device, dtype=_F32)
+        dz = torch.empty_like(z)
+        sfx = _suffix(z)
+        if bn_channel_ok(z):
+            call(f"ppea_bn_bwd_channel_{sfx}", ptr(dt), ptr(z), None, stats, None, 1.0 / float(N * HW), None, ptr(dz), None,
+                 ptr(sums), ACT_RELU, N, C, HW, stream_ptr())
+        else:
+            err = getattr(_abi.lib, f"ppea_bn_bwd_reduce_final_{sfx}")(ptr(dt), ptr(z), None, stats, None, ptr(sums), ACT_RELU,
+                                                                       N, C, HW, stream_ptr())
+            if err == -1:
+                partial = torch.empty(C * N * 3, device=z.device, dtype=_F32)
+                call(f"ppea_bn_bwd_reduce_{sfx}", ptr(dt), ptr(z), None, stats, None, ptr(partial), ACT_RELU, N, C, HW,
+                     stream_ptr())
+                call("ppea_bn_bwd_finalize_f32", ptr(partial), N, C, ptr(sums), stream_ptr())
+            else:
+                _abi.check(err, "ppea_bn_bwd_reduce_final")
+            call(f"ppea_bn_bwd_apply_{sfx}", ptr(dt), ptr(z), None, stats, None, ptr(sums), 1.0 / float(N * HW), ptr(dz), None,
+                 ACT_RELU, N, C, HW, stream_ptr())
+        dg = sums[1].to(ctx.pdt[0]) if ctx.needs_input_grad[2] else None
+        db = sums[0].to(ctx.pdt[1]) if ctx.needs_input_grad[3] else None
+        return dz, None, dg, db, None, None, None, None, None, None
+
+
+def dwconv_lk_bn_supported(shape, K, KS):
+    """The fused form needs the MFMA depthwise kernel (bf16 input of `shape`, k in 31/29/27/13, 5x5 branch) and a shape
+    that kernel serves."""
+    N, C, H, W = shape
+    return K in _MFMA_K and KS == 5 and _abi.lib.ppea_dwconv_lk_stats_partials(N, C, H, W, K, KS) > 0
+
+
+def dwconv_lk_bn(z, sums, bn, w_big, w_small):
+    """-> (DW_k(relu(BN(z))), DW_5(relu(BN(z))), stats [2,C] = mean | invstd).  `sums`: the partial sums the 1x1 conv that
+    produced z left (pwconv_frozen(..., want_sums=True)).  Frozen depthwise filters only; updates bn's running statistics."""
+    # (the filters are passed as they are: the packed fragment images are cached per weight OBJECT)
+    assert not w_big.requires_grad and not w_small.requires_grad
+    return _DwConvLKBn.apply(z, sums, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum,
+                             w_big, w_small)
+
+
 def dwconv_lk(x, w_big, w_small=None, want_sums=False):
     """(DW_k(x), DW_ks(x)) with stride 1 / pad k//2 / no bias; second is None without w_small.
     want_sums: -> (y_big, y_small, sums [2, C, P, 2] or None): per-channel partial (sum, sum of squares) of both outputs

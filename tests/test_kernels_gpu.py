@@ -508,11 +508,16 @@ def test_pwconv_v2_lds_dma_ring_every_tile(device, monkeypatch, tile, B, M, K, H
         assert (mine != old).float().mean() < 0.02
 
 
+@pytest.mark.parametrize("v2", ["1", "0"])
 @pytest.mark.parametrize("B,M,N,H,W", [(2, 128, 128, 12, 40), (3, 288, 128, 48, 160), (2, 100, 36, 6, 20),
-                                       (12, 1152, 512, 12, 40), (1, 32, 256, 3, 8)])
-def test_pwgrad_mfma(device, B, M, N, H, W):
-    """Pixel-contraction GEMM (weight gradients) + row sums vs fp32 einsum of the bf16 operands."""
+                                       (12, 1152, 512, 12, 40), (1, 32, 256, 3, 8), (2, 130, 34, 8, 32),
+                                       (12, 288, 128, 48, 160), (5, 64, 514, 4, 8)])
+def test_pwgrad_mfma(device, monkeypatch, v2, B, M, N, H, W):
+    """Pixel-contraction GEMM (weight gradients) + row sums vs fp32 einsum of the bf16 operands: v2 (three-stage LDS ring
+    filled by LDS-DMA, planes that are a multiple of the 32-pixel step) and v1 (any plane with HW % 8 == 0); ragged row /
+    column tiles, result widths that are not a multiple of 4, 1 .. 11 splits."""
     from ppeadepth import ops
+    monkeypatch.setenv("PPEA_PWGRAD_V2", v2)
     g = _g(M + N)
     p = torch.randn(B, M, H, W, generator=g).bfloat16()
     q = torch.randn(B, N, H, W, generator=g).bfloat16()
@@ -1265,3 +1270,49 @@ def test_decoder_adapter_split_equals_the_concatenated_form(device):
     got = [y.float().cpu(), ad_.grad.float().cpu(), bd_.grad.float().cpu()] + [p.grad.float().cpu() for p in adg.parameters()]
     for u, v in zip(got, ref):
         assert u.shape == v.shape and (u - v).abs().max() <= v.abs().max() * 2 ** -5
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(12, 128, 48, 160, 31), (12, 256, 24, 80, 29), (12, 512, 12, 40, 27),
+                                       (6, 1024, 6, 20, 13), (3, 64, 20, 36, 13), (2, 64, 50, 37, 31)])
+def test_dwconv_fused_input_batchnorm_relu_equals_the_separate_launches(device, N, C, H, W, K):
+    """RepLKBlock forward (rka.py:305-308): pw1's BatchNorm + ReLU applied inside the depthwise kernel's staging pass
+    (statistics finalised per wave from the 1x1 conv's epilogue sums) against the separate launches -- statistics from the
+    same sums, flat apply, then the depthwise conv: forward outputs, saved statistics and running statistics BIT-IDENTICAL
+    (same arithmetic, same rounding points; zero padding of the ACTIVATED tensor, incl. planes whose width is not a
+    multiple of 8), gradients to rounding."""
+    from ppeadepth import ops
+    from ppeadepth.batchnorm import BatchNorm2d
+    g = _g(N + C + K)
+    Kin = 64
+    x = torch.randn(N, Kin, H, W, generator=g).bfloat16().to(device)
+    wpw = (torch.randn(C, Kin, 1, 1, generator=g) / Kin ** 0.5).to(device)
+    wb = (torch.randn(C, 1, K, K, generator=g) / K).to(device)
+    ws = (torch.randn(C, 1, 5, 5, generator=g) / 5).to(device)
+    gb, gs = (torch.randn(N, C, H, W, generator=g).bfloat16().to(device) for _ in range(2))
+    if (H * W) % 8:
+        pytest.skip("the 1x1 conv's MFMA path (and its statistics epilogue) needs HW % 8 == 0")
+    assert ops.dwconv_lk_bn_supported((N, C, H, W), K, 5)
+    res = []
+    for fused in (False, True):
+        bn = BatchNorm2d(C).to(device)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, generator=_g(1)) + 0.5)
+            bn.bias.copy_(torch.randn(C, generator=_g(2)) * 0.2)
+        xl = x.clone().requires_grad_(True)
+        z, sums = ops.pwconv_frozen(xl, wpw, want_sums=True)
+        if fused:
+            yb, ys, st = ops.dwconv_lk_bn(z, sums, bn, wb, ws)
+            mean, invstd = st[0], st[1]
+        else:
+            mean, _var, invstd = ops.bn_batch_stats_from_sums(sums, N * H * W, bn.eps, bn.momentum, bn.running_mean,
+                                                              bn.running_var)
+            t = ops.bn_act_apply(z, bn.weight, bn.bias, mean, invstd, act=ops.ACT_RELU)
+            yb, ys = ops.dwconv_lk(t, wb, ws)
+        torch.autograd.backward([yb, ys], [gb, gs])
+        res.append((yb, ys, mean.clone(), invstd.clone(), bn.running_mean.clone(), bn.running_var.clone(), xl.grad,
+                    bn.weight.grad, bn.bias.grad))
+    a, b = res
+    for k in range(6):
+        assert torch.equal(a[k], b[k]), k
+    for k in (6, 7, 8):
+        assert rel_err(b[k].float(), a[k].float()) < 2e-2, k

@@ -31,7 +31,7 @@ for pmc in FETCH_SIZE WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_
 done
 python3 tools/pmc_summary.py $OUT/${R}_pmc_kernels.csv $dirs || exit 1
 # 4. per-shape tables
-python3 tools/bench_pw3.py --lib > $OUT/${R}_pwconv_shapes.txt 2>/dev/null || exit 1
+python3 tools/bench_pw4.py --lib > $OUT/${R}_pwconv_shapes.txt 2>/dev/null || exit 1
 echo "pwconv table done"
 python3 tools/bench_conv.py > $OUT/${R}_conv_layers_vs_library.txt 2>/dev/null || exit 1
 echo "conv table done"
