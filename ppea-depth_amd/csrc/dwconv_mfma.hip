@@ -336,12 +336,18 @@ __device__ __forceinline__ void stream_first(bf16x8 (&ring)[RING], const TileBas
     (stream_read<K, KS, NS, STRIDE_B, SM_ROW0, Is>(ring[Is % RING], tb), ...);
 }
 
-template <int K, int KS, int MODE, int NS, int STRIDE_B, int SM_ROW0, int I>
+// `epi`: the PREVIOUS tile's epilogue (convert + stores), run EPI_AT steps into this tile's stream: by then the previous
+// tile's last MFMAs have retired (no wait on the accumulator) and the conversions / address arithmetic / stores issue in
+// the shadow of this tile's MFMAs instead of between two tiles.
+constexpr int EPI_AT = 6;
+
+template <int K, int KS, int MODE, int NS, int STRIDE_B, int SM_ROW0, int I, typename Epi>
 __device__ __forceinline__ void stream_step(f32x4 (&accb)[2], f32x4& accs, bf16x8 (&cur)[RING], bf16x8 (&nxt)[RING],
                                             const TileBase& tc, const TileBase& tn, const bf16x8 (&bfb)[K][NS],
-                                            const bf16x8 (&bfs)[(KS > 0 ? KS : 1)][1]) {
+                                            const bf16x8 (&bfs)[(KS > 0 ? KS : 1)][1], Epi&& epi) {
     constexpr int TOTAL = K * NS + KS;
     if constexpr (I < TOTAL) {
+        if constexpr (I == EPI_AT) epi();
         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[I % RING]) : "i"(DIST - 1));
         if constexpr (I < K * NS)
             accb[I & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfb[I / NS][I % NS], cur[I % RING], accb[I & 1], 0, 0, 0);
@@ -352,7 +358,7 @@ __device__ __forceinline__ void stream_step(f32x4 (&accb)[2], f32x4& accs, bf16x
         constexpr int J = I + DIST;
         if constexpr (J < TOTAL) stream_read<K, KS, NS, STRIDE_B, SM_ROW0, J>(cur[J % RING], tc);
         else stream_read<K, KS, NS, STRIDE_B, SM_ROW0, J - TOTAL>(nxt[(J - TOTAL) % RING], tn);
-        stream_step<K, KS, MODE, NS, STRIDE_B, SM_ROW0, I + 1>(accb, accs, cur, nxt, tc, tn, bfb, bfs);
+        stream_step<K, KS, MODE, NS, STRIDE_B, SM_ROW0, I + 1>(accb, accs, cur, nxt, tc, tn, bfb, bfs, epi);
     }
 }
 
@@ -567,35 +573,53 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
         TileBase tc = tile_base(0, 0);
         stream_first<K, KS, GE::NS, STRIDE_B, SM_ROW0>(ringA, tc, std::make_integer_sequence<int, DIST>{});
         RowOffs ro = row_offsets(it, C, c, H, W, 0, lane);
-        auto one_tile = [&](bf16x8 (&cur)[RING], bf16x8 (&nxt_ring)[RING], int t) {
+        // two accumulator sets alternate by tile parity (like the rings); the set a tile leaves behind is converted and
+        // stored EPI_AT steps into the next tile's stream (stream_step)
+        f32x4 accA[2], accB[2], accsA, accsB;
+        RowOffs ro_pend = ro;
+        int xt_pend = 0;
+        bool pend = false;
+        auto epilogue = [&](const f32x4 (&pb)[2], const f32x4& ps) {
+            const f32x4 acc = pb[0] + pb[1];
+            store_tile(out0, acc, ro_pend, W, xt_pend, lane);
+            if constexpr (MODE == 0 && KS > 0) store_tile(out1, ps, ro_pend, W, xt_pend, lane);
+            if constexpr (MODE == 0) {
+                if (stats != nullptr) {                      // wave-uniform
+                    tile_stats(acc, ro_pend, W, xt_pend, lane, st_sb, st_qb);
+                    if constexpr (KS > 0) tile_stats(ps, ro_pend, W, xt_pend, lane, st_ss, st_qs);
+                }
+            }
+        };
+        auto one_tile = [&](bf16x8 (&cur)[RING], bf16x8 (&nxt_ring)[RING], f32x4 (&mine)[2], f32x4& mine_s,
+                            const f32x4 (&other)[2], const f32x4& other_s, int t) {
             int mt2 = mt, nt2 = nt + 1;
             if (nt2 == ntiles_x) { nt2 = 0; ++mt2; }
             const bool last = t + 1 >= ntiles;
             const TileBase tn = last ? tc : tile_base(mt2, nt2);        // last tile: harmless re-reads, drained below
-            f32x4 accb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            f32x4 accs = {0.f, 0.f, 0.f, 0.f};
+            mine[0] = {0.f, 0.f, 0.f, 0.f};
+            mine[1] = {0.f, 0.f, 0.f, 0.f};
+            mine_s = {0.f, 0.f, 0.f, 0.f};
             PROF_T(t_mac0);
-            stream_step<K, KS, MODE, GE::NS, STRIDE_B, SM_ROW0, 0>(accb, accs, cur, nxt_ring, tc, tn, bf_big, bf_small);
+            stream_step<K, KS, MODE, GE::NS, STRIDE_B, SM_ROW0, 0>(mine, mine_s, cur, nxt_ring, tc, tn, bf_big, bf_small,
+                                                                   [&]() { if (pend) epilogue(other, other_s); });
             PROF_T(t_mac1);
             PROF_ADD(2, t_mac0, t_mac1);
-            const f32x4 acc = accb[0] + accb[1];
-            store_tile(out0, acc, ro, W, it.x0 + nt * 16, lane);
-            if constexpr (MODE == 0 && KS > 0) store_tile(out1, accs, ro, W, it.x0 + nt * 16, lane);
-            if constexpr (MODE == 0) {
-                if (stats != nullptr) {                      // wave-uniform
-                    tile_stats(acc, ro, W, it.x0 + nt * 16, lane, st_sb, st_qb);
-                    if constexpr (KS > 0) tile_stats(accs, ro, W, it.x0 + nt * 16, lane, st_ss, st_qs);
-                }
-            }
+            ro_pend = ro;
+            xt_pend = it.x0 + nt * 16;
+            pend = true;
             if (mt2 != mt && !last) ro = row_offsets(it, C, c, H, W, mt2, lane);
             mt = mt2; nt = nt2; tc = tn;
-            PROF_T(t_epi);
-            PROF_ADD(3, t_mac1, t_epi);
         };
         for (int t = 0; t < ntiles; t += 2) {
-            one_tile(ringA, ringB, t);
-            if (t + 1 < ntiles) one_tile(ringB, ringA, t + 1);
+            one_tile(ringA, ringB, accA, accsA, accB, accsB, t);
+            if (t + 1 < ntiles) one_tile(ringB, ringA, accB, accsB, accA, accsA, t + 1);
         }
+        PROF_T(t_epi0);
+        if (pend) {                                              // the item's last tile
+            if (ntiles & 1) epilogue(accA, accsA); else epilogue(accB, accsB);
+        }
+        PROF_T(t_epi);
+        PROF_ADD(3, t_epi0, t_epi);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the look-ahead reads of the last tile
         PROF_T(t_item_end);
         PROF_ADD(4, t_item, t_item_end);
