@@ -247,6 +247,25 @@ def main():
             e_ev.synchronize()
             replay_us[kind] = s_ev.elapsed_time(e_ev) / 20 * 1e3
     ops.PROFILE_REPLAY.clear()
+    # the PLAIN 31x31 (+5x5) forward -- round 1 / 2's roofline kernel; in the step its place is taken by the variant with
+    # pw1's BatchNorm + ReLU fused into the staging pass -- 20 launches back to back on the launch stream
+    plain_us = None
+    if args.dtype == "bf16" and rank == 0:
+        with torch.cuda.stream(engine.stream), torch.no_grad():
+            C0_ = 128 if args.rep_size == "b" else 192
+            xx = torch.randn(B, C0_, H // 4, W // 4, device=device).bfloat16()
+            wb_ = torch.randn(C0_, 1, 31, 31, device=device) / 31
+            ws_ = torch.randn(C0_, 1, 5, 5, device=device) / 5
+            for _ in range(3):
+                ops.dwconv_lk(xx, wb_, ws_)
+            s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_ev.record()
+            for _ in range(20):
+                ops.dwconv_lk(xx, wb_, ws_)
+            e_ev.record()
+            e_ev.synchronize()
+            plain_us = s_ev.elapsed_time(e_ev) / 20 * 1e3
+            del xx, wb_, ws_
     barrier()
     # second roofline: the kernel family that carries the most wall time of the step (profiles/r02_wall_attribution.txt) --
     # the NCHW 1x1-conv GEMM, on its largest stage-2 shape (ConvFFN pw1, 512 -> 2048 at 12x40, the batch of this run);
@@ -301,7 +320,19 @@ def main():
             if args.dtype == "bf16":
                 # banded-Toeplitz MFMA kernel: (31 rows x 2 chunks + 5) v_mfma_f32_16x16x32_bf16 per 16x16 tile
                 executed = (plane / 256.0) * (31 * 2 + 5) * 2.0 * 16 * 16 * 32
-                roof.update({"name": "dwconv_mfma_kernel<31,5,0,5>",
+                from ppeadepth.networks import replknet_adapter as _rka
+                fused_bn = bool(_rka.DW_BN_FUSE and not pdist.collectives_on())
+                if plain_us is not None:
+                    roof["plain_kernel"] = {
+                        "name": "dwconv_mfma_kernel<31,5,0,5,false> (no fused input BatchNorm: rounds 1-2's roofline kernel)",
+                        "back_to_back_us": round(plain_us, 1),
+                        "achieved": round(bytes_alg / plain_us / 1e3, 1), "unit": "GB/s",
+                        "frac": round(bytes_alg / plain_us / 1e3 / HBM_PEAK_GBS, 4),
+                        "mfma_frac": round(executed / plain_us / 1e6 / MFMA_BF16_PEAK_TF, 3)}
+                if fused_bn:
+                    roof["kernel"] += "; as launched in the step: pw1's BatchNorm + ReLU applied in the staging pass " \
+                                      "(the separate BN pass it replaces would move 47 MB more)"
+                roof.update({"name": "dwconv_mfma_kernel<31,5,0,5,%s>" % ("true" if fused_bn else "false"),
                              "binding_roof": "bf16 MFMA (useful AI %d F/B; Toeplitz band executes %.2fx the useful MACs)"
                                              % (round(useful / bytes_alg), executed / useful),
                              "mfma_executed_tflops": round(executed / t_k / 1e12, 1),
@@ -312,7 +343,7 @@ def main():
                     # HBM-side bytes per launch: parsed from the committed PMC summary (separate rocprofv3 --pmc
                     # FETCH_SIZE / WRITE_SIZE passes over tools/pmc_target.py, same shape; KB per dispatch;
                     # FETCH_SIZE doubled for 16-byte-per-lane loads on gfx950 as MI355X_MICROARCH.md prescribes)
-                    pmc = pmc_traffic("dwconv_mfma_kernel<31, 5, 0, 5>")
+                    pmc = pmc_traffic("dwconv_mfma_kernel<31, 5, 0, 5")
                     if pmc is not None:
                         roof["traffic"] = pmc[0]
                         roof["traffic_note"] = (f"{pmc[1]}: FETCH_SIZE x2 + WRITE_SIZE per dispatch = "
