@@ -22,6 +22,7 @@
 // dgrad: second input, same accumulator) costs 5 more MFMAs per tile.
 // Replaces nn.Conv2d(groups=C) at networks/replknet_adapter.py:225-239 under bf16 autocast.
 #include "common.h"
+#include <cstdlib>
 #include <utility>
 
 #ifdef DW_PROF
@@ -362,6 +363,103 @@ __device__ __forceinline__ void stream_step(f32x4 (&accb)[2], f32x4& accs, bf16x
     }
 }
 
+// ---- window sharing between vertically stacked tiles (WS) ----------------------------------------------------------
+// A 48-row item is a column of MTL = 3 stacked 16-row tiles per column tile.  The A fragment of (tile t, filter row ky)
+// is the 16-row window of the staged plane that starts at row 16 t + ky: window w = 16 t + ky serves every tile t with
+// 0 <= w - 16 t < K, i.e. up to two tiles.  One COLUMN is therefore one stream of (16 (MTL - 1) + K) x NS window reads
+// (+ MTL x KS small-kernel reads) feeding MTL x (K x NS + KS) MFMAs -- 141 LDS reads per 201 MFMAs at k = 31 instead of
+// 201, which is what the LDS-bound stream (four waves x 1 KB per ~20 cycles = 80 % of the 256 B/clk) needed.
+// The schedule is a compile-time table; tile t's accumulators are final after window 16 t + K - 1 and are converted and
+// stored EPI_DELAY steps later, inside the same stream; the last tile's leave with the column and are stored EPI_AT
+// steps into the next column's stream (its accumulator slot alternates by column parity).
+constexpr int EPI_DELAY = 6;
+// a shallower read-ahead than the per-tile stream's: a window feeds up to two MFMAs, and the column's accumulators (up to
+// 12 f32x4) need the registers
+constexpr int CT_DIST = 8, CT_RING = 9;
+
+template <int K, int KS, int NS, int MTL>
+struct CtSched {
+    static constexpr int WN = 16 * (MTL - 1) + K;
+    static constexpr int TOTAL = WN * NS + MTL * KS;
+    static constexpr int SM_ROW0 = K / 2 - (KS > 0 ? KS : 5) / 2;
+    struct Step { int kind, w, s, t, ky; };                 // kind 0: big window (w, chunk s); 1: small (tile t, row ky)
+    static constexpr Step at(int J) {
+        int j = 0;
+        for (int w = 0; w < WN; ++w) {
+            for (int s = 0; s < NS; ++s) { if (j == J) return {0, w, s, 0, 0}; ++j; }
+            if (KS > 0) {
+                const int r = w - (SM_ROW0 + KS - 1);
+                if (r >= 0 && r % 16 == 0 && r / 16 < MTL)
+                    for (int ky = 0; ky < KS; ++ky) { if (j == J) return {1, 0, 0, r / 16, ky}; ++j; }
+            }
+        }
+        return {-1, 0, 0, 0, 0};
+    }
+    static constexpr int final_idx(int t) {                  // the step after which tile t receives no more MFMAs
+        int j = 0, last = 0;
+        for (int w = 0; w < WN; ++w) {
+            for (int s = 0; s < NS; ++s) { if (w == 16 * t + K - 1) last = j; ++j; }
+            if (KS > 0) {
+                const int r = w - (SM_ROW0 + KS - 1);
+                if (r >= 0 && r % 16 == 0 && r / 16 < MTL) j += KS;
+            }
+        }
+        return last;
+    }
+};
+
+template <int K, int KS, int NS, int MTL, int STRIDE_B, int J>
+__device__ __forceinline__ void ct_read(bf16x8& slot, const TileBase& tb) {
+    using S = CtSched<K, KS, NS, MTL>;
+    constexpr typename S::Step st = S::at(J);
+    if constexpr (st.kind == 0) ds_read128_async<st.w * STRIDE_B + st.s * 64>(slot, tb.big);
+    else ds_read128_async<(16 * st.t + S::SM_ROW0 + st.ky) * STRIDE_B>(slot, tb.small);
+}
+
+template <int K, int KS, int NS, int MTL, int STRIDE_B, int... Is>
+__device__ __forceinline__ void ct_first(bf16x8 (&ring)[CT_RING], const TileBase& tb, std::integer_sequence<int, Is...>) {
+    (ct_read<K, KS, NS, MTL, STRIDE_B, Is>(ring[Is % CT_RING], tb), ...);
+}
+
+// accb[MTL + 1][NS], accs[MTL + 1]: slot MTL is the last tile's alternate (columns of odd parity)
+template <int K, int KS, int MODE, int NS, int MTL, int STRIDE_B, int PAR, int I, typename EpiT, typename EpiPrev>
+__device__ __forceinline__ void ct_step(f32x4 (&accb)[MTL + 1][NS], f32x4 (&accs)[MTL + 1], bf16x8 (&cur)[CT_RING],
+                                        bf16x8 (&nxt)[CT_RING], const TileBase& tc, const TileBase& tn,
+                                        const bf16x8 (&bfb)[K][NS], const bf16x8 (&bfs)[(KS > 0 ? KS : 1)][1],
+                                        EpiT&& epi_tile, EpiPrev&& epi_prev) {
+    using S = CtSched<K, KS, NS, MTL>;
+    if constexpr (I < S::TOTAL) {
+        if constexpr (I == EPI_AT) epi_prev();
+#define PPEA_CT_EPI(T_)                                                                                     \
+        if constexpr (T_ < MTL - 1) { if constexpr (I == S::final_idx(T_) + EPI_DELAY) epi_tile(std::integral_constant<int, T_>{}); }
+        PPEA_CT_EPI(0) PPEA_CT_EPI(1) PPEA_CT_EPI(2)
+#undef PPEA_CT_EPI
+        constexpr typename S::Step st = S::at(I);
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur[I % CT_RING]) : "i"(CT_DIST - 1));
+        if constexpr (st.kind == 0) {
+#define PPEA_CT_MAC(T_)                                                                                     \
+            if constexpr (T_ < MTL && st.w - 16 * T_ >= 0 && st.w - 16 * T_ < K) {                          \
+                constexpr int sl = (T_ == MTL - 1 && PAR) ? MTL : T_;                                       \
+                accb[sl][st.s] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfb[st.w - 16 * T_][st.s], cur[I % CT_RING],     \
+                                                                          accb[sl][st.s], 0, 0, 0);         \
+            }
+            PPEA_CT_MAC(0) PPEA_CT_MAC(1) PPEA_CT_MAC(2)
+#undef PPEA_CT_MAC
+        } else {
+            constexpr int sl = (st.t == MTL - 1 && PAR) ? MTL : st.t;
+            if constexpr (MODE == 0)
+                accs[sl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfs[st.ky][0], cur[I % CT_RING], accs[sl], 0, 0, 0);
+            else
+                accb[sl][st.ky % NS] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfs[st.ky][0], cur[I % CT_RING],
+                                                                                accb[sl][st.ky % NS], 0, 0, 0);
+        }
+        constexpr int J = I + CT_DIST;
+        if constexpr (J < S::TOTAL) ct_read<K, KS, NS, MTL, STRIDE_B, J>(cur[J % CT_RING], tc);
+        else ct_read<K, KS, NS, MTL, STRIDE_B, J - S::TOTAL>(nxt[(J - S::TOTAL) % CT_RING], tn);
+        ct_step<K, KS, MODE, NS, MTL, STRIDE_B, PAR, I + 1>(accb, accs, cur, nxt, tc, tn, bfb, bfs, epi_tile, epi_prev);
+    }
+}
+
 // The MFMAs take the Toeplitz fragment as the A operand and the input rows as B (both fragment layouts are
 // "index = lane & 15, k = 8 * (lane >> 4) + j", so the registers are the same either way): the accumulator then
 // holds the TRANSPOSED tile -- lane (y = lane & 15, g = lane >> 4) owns columns 4g..4g+3 of image row y, four
@@ -412,7 +510,7 @@ __device__ __forceinline__ void tile_stats(const f32x4& acc, const RowOffs& ro, 
 
 // MODE 0: fwd  (in0 = x; out0 = y_big, out1 = y_small if KS)
 // MODE 1: dgrad (in0 = dy_big, in1 = dy_small if KS; out0 = dx), filters flipped
-template <int K, int KS, int MODE, int NSEG, bool BN = false>
+template <int K, int KS, int MODE, int NSEG, bool BN = false, bool WS = false>
 __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     const uint16_t* __restrict__ in0, const uint16_t* __restrict__ in1, const uint16_t* __restrict__ w_big,
     const uint16_t* __restrict__ w_small, uint16_t* __restrict__ out0, uint16_t* __restrict__ out1, int N, int C,
@@ -568,7 +666,65 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
             return tb;
         };
         const int ntiles = ntiles_m * ntiles_x;
-        bf16x8 ringA[RING], ringB[RING];
+        bf16x8 ringA[WS ? CT_RING : RING], ringB[WS ? CT_RING : RING];
+        if constexpr (WS) {
+            // window sharing (see CtSched): the item is ONE plane band of exactly 48 rows (the host launches this variant
+            // only then), processed column by column
+            constexpr int MTL = 3, NS = GE::NS;
+            f32x4 accb[MTL + 1][NS], accs[MTL + 1];
+            RowOffs ro3[MTL];
+#pragma unroll
+            for (int t = 0; t < MTL; ++t) ro3[t] = row_offsets(it, C, c, H, W, t, lane);
+            TileBase tc = tile_base(0, 0);
+            ct_first<K, KS, NS, MTL, STRIDE_B>(ringA, tc, std::make_integer_sequence<int, CT_DIST>{});
+            int xt_prev = 0;
+            bool pend = false;
+            auto store3 = [&](const f32x4 (&pb)[NS], const f32x4& ps, const RowOffs& ro, int xt) {
+                f32x4 acc = pb[0];
+                if constexpr (NS == 2) acc = pb[0] + pb[1];
+                store_tile(out0, acc, ro, W, xt, lane);
+                if constexpr (MODE == 0 && KS > 0) store_tile(out1, ps, ro, W, xt, lane);
+                if constexpr (MODE == 0) {
+                    if (stats != nullptr) {
+                        tile_stats(acc, ro, W, xt, lane, st_sb, st_qb);
+                        if constexpr (KS > 0) tile_stats(ps, ro, W, xt, lane, st_ss, st_qs);
+                    }
+                }
+            };
+            auto one_ct = [&](auto par_c, bf16x8 (&cur)[CT_RING], bf16x8 (&nxt_ring)[CT_RING], int nt, bool last) {
+                constexpr int PAR = decltype(par_c)::value;
+                constexpr int LS = PAR ? MTL : MTL - 1, PS = PAR ? MTL - 1 : MTL;   // this / the previous column's last-tile slot
+                const TileBase tn = last ? tc : tile_base(0, nt + 1);
+#pragma unroll
+                for (int t = 0; t < MTL - 1; ++t) {
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) accb[t][q] = {0.f, 0.f, 0.f, 0.f};
+                    accs[t] = {0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int q = 0; q < NS; ++q) accb[LS][q] = {0.f, 0.f, 0.f, 0.f};
+                accs[LS] = {0.f, 0.f, 0.f, 0.f};
+                const int xt = it.x0 + nt * 16;
+                PROF_T(t_mac0);
+                ct_step<K, KS, MODE, NS, MTL, STRIDE_B, PAR, 0>(
+                    accb, accs, cur, nxt_ring, tc, tn, bf_big, bf_small,
+                    [&](auto tcst) { constexpr int T = decltype(tcst)::value; store3(accb[T], accs[T], ro3[T], xt); },
+                    [&]() { if (pend) store3(accb[PS], accs[PS], ro3[MTL - 1], xt_prev); });
+                PROF_T(t_mac1);
+                PROF_ADD(2, t_mac0, t_mac1);
+                xt_prev = xt;
+                pend = true;
+                tc = tn;
+            };
+            for (int nt = 0; nt < ntiles_x; nt += 2) {
+                one_ct(std::integral_constant<int, 0>{}, ringA, ringB, nt, nt + 1 >= ntiles_x);
+                if (nt + 1 < ntiles_x) one_ct(std::integral_constant<int, 1>{}, ringB, ringA, nt + 1, nt + 2 >= ntiles_x);
+            }
+            if (pend) {                                          // the last column's last tile
+                if (ntiles_x & 1) store3(accb[MTL - 1], accs[MTL - 1], ro3[MTL - 1], xt_prev);
+                else store3(accb[MTL], accs[MTL], ro3[MTL - 1], xt_prev);
+            }
+        } else {
         int mt = 0, nt = 0;
         TileBase tc = tile_base(0, 0);
         stream_first<K, KS, GE::NS, STRIDE_B, SM_ROW0>(ringA, tc, std::make_integer_sequence<int, DIST>{});
@@ -620,6 +776,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
         }
         PROF_T(t_epi);
         PROF_ADD(3, t_epi0, t_epi);
+        }                                                        // !WS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the look-ahead reads of the last tile
         PROF_T(t_item_end);
         PROF_ADD(4, t_item, t_item_end);
@@ -647,7 +804,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
 
 // stats / wpc_out: forward only -- per-wave partial sums for the BatchNorm pair (see the kernel); wpc_out != nullptr:
 // do not launch, return the number of waves per channel (= partials per channel) the launch would use
-template <int K, int KS, int MODE, int NSEG, bool BN = false>
+template <int K, int KS, int MODE, int NSEG, bool BN = false, bool WS = false>
 int launch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0,
            uint16_t* o1, int N, int C, int H, int W, hipStream_t st, float* stats = nullptr, int* wpc_out = nullptr,
            const BnIn* bn = nullptr) {
@@ -683,7 +840,10 @@ int launch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const u
     if (wpc_out != nullptr) { *wpc_out = wpc; return 0; }
     const long total_waves = (long)C * wpc;
     const size_t lds = (size_t)WAVES * region;
-    auto kern = dwconv_mfma_kernel<K, KS, MODE, NSEG, BN>;
+    if constexpr (WS) {
+        if (!(G == 1 && band == 48 && H % 48 == 0)) return PPEA_ERR_UNSUPPORTED;       // every item: one 48-row band
+    }
+    auto kern = dwconv_mfma_kernel<K, KS, MODE, NSEG, BN, WS>;
     const BnIn bnv = bn != nullptr ? *bn : BnIn{nullptr, 0, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     static bool attr_done = false;
     if (!attr_done) {
@@ -708,6 +868,22 @@ int launch_k(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const
              uint16_t* o1, int N, int C, int H, int W, hipStream_t st, float* stats, int* wpc_out, const BnIn* bn) {
     const long c5 = staged_cols<K>(W, 5), c3 = staged_cols<K>(W, 3), c2 = staged_cols<K>(W, 2);
     const int nseg = (c5 <= c3 && c5 <= c2) ? 5 : (c3 <= c2 ? 3 : 2);
+    if constexpr (K == 31 && KS == 5) {
+        // window sharing between the three stacked tiles of a 48-row plane (stage 0 at 192 x 640): launch() refuses the
+        // variant unless every item is one 48-row band, and the generic kernel takes over below
+        static const bool ws_on = !(getenv("PPEA_DW_WS") != nullptr && getenv("PPEA_DW_WS")[0] == '0');
+        if (ws_on && nseg == 5 && wpc_out == nullptr) {
+            int err;
+            if constexpr (MODE == 0) {
+                err = bn != nullptr ? launch<K, KS, MODE, 5, true, true>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, nullptr, bn)
+                                    : launch<K, KS, MODE, 5, false, true>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, nullptr, nullptr);
+            } else {
+                err = bn != nullptr ? PPEA_ERR_UNSUPPORTED
+                                    : launch<K, KS, MODE, 5, false, true>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, nullptr, nullptr);
+            }
+            if (err != PPEA_ERR_UNSUPPORTED) return err;
+        }
+    }
     if constexpr (MODE == 0 && KS == 5) {
         if (bn != nullptr) {                                     // fused input BatchNorm + ReLU (RepLKBlock forward)
             if (nseg == 5) return launch<K, KS, MODE, 5, true>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out, bn);

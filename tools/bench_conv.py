@@ -83,8 +83,16 @@ def main():
                 t_d = timeit(lambda: ops.conv_nhwc_raw(dz, wt, None, Cin, k, k, 1, k - 1 - pad, False, stride, H, W, 0, False))
         ws = torch.empty(ops._abi.lib.ppea_conv_wgrad_workspace_bytes(N, Cin, C8, k, k, stride, Ho, Wo) // 4, device=dev)
         dw = torch.empty(C8, Cin, k, k, device=dev, dtype=torch.bfloat16)
-        t_w = timeit(lambda: ops.call("ppea_conv_wgrad_nhwc_bf16", ops._raw(dz), ops._raw(x), ops.ptr(dw), 1, ops.ptr(ws), N, H, W,
-                                      Cin, C8, k, k, stride, pad, int(reflect), Ho, Wo, ops.stream_ptr()))
+        if image_fed:
+            # the image-fed layers (stem[0], pose conv1) take the row-packed kernels in the step (ops._ConvImage): time THOSE
+            cin_real = 3 if k == 3 else 6
+            wsi = torch.empty(ops._abi.lib.ppea_conv_image_wgrad_workspace_bytes(N, Cout, k, Ho, Wo) // 4, device=dev)
+            dwi = torch.empty(Cout, cin_real, k, k, device=dev, dtype=torch.bfloat16)
+            t_w = timeit(lambda: ops.call("ppea_conv_image_wgrad_bf16", ops._raw(dz), ops._raw(x), ops.ptr(dwi), 1, ops.ptr(wsi), N, H, W,
+                                          cin_real, Cout, k, 2, pad, Ho, Wo, ops.stream_ptr()))
+        else:
+            t_w = timeit(lambda: ops.call("ppea_conv_wgrad_nhwc_bf16", ops._raw(dz), ops._raw(x), ops.ptr(dw), 1, ops.ptr(ws), N, H, W,
+                                          Cin, C8, k, k, stride, pad, int(reflect), Ho, Wo, ops.stream_ptr()))
         # ---- library (what the step used before): pad kernel + conv + bias/act kernels are NOT counted, conv only ---
         xl = (F.pad(x, (1, 1, 1, 1), mode="reflect") if reflect else x).contiguous(memory_format=torch.channels_last)
         wl = w.detach().contiguous(memory_format=torch.channels_last)
