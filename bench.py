@@ -324,7 +324,7 @@ def main():
                 fused_bn = bool(_rka.DW_BN_FUSE and not pdist.collectives_on())
                 if plain_us is not None:
                     roof["plain_kernel"] = {
-                        "name": "dwconv_mfma_kernel<31,5,0,5,false> (no fused input BatchNorm: rounds 1-2's roofline kernel)",
+                        "name": "dwconv_mfma_kernel<31,5,0,5,false,true> (no fused input BatchNorm: rounds 1-2's roofline kernel)",
                         "back_to_back_us": round(plain_us, 1),
                         "achieved": round(bytes_alg / plain_us / 1e3, 1), "unit": "GB/s",
                         "frac": round(bytes_alg / plain_us / 1e3 / HBM_PEAK_GBS, 4),
@@ -332,7 +332,7 @@ def main():
                 if fused_bn:
                     roof["kernel"] += "; as launched in the step: pw1's BatchNorm + ReLU applied in the staging pass " \
                                       "(the separate BN pass it replaces would move 47 MB more)"
-                roof.update({"name": "dwconv_mfma_kernel<31,5,0,5,%s>" % ("true" if fused_bn else "false"),
+                roof.update({"name": "dwconv_mfma_kernel<31,5,0,5,%s,true>" % ("true" if fused_bn else "false"),
                              "binding_roof": "bf16 MFMA (useful AI %d F/B; Toeplitz band executes %.2fx the useful MACs)"
                                              % (round(useful / bytes_alg), executed / useful),
                              "mfma_executed_tflops": round(executed / t_k / 1e12, 1),
