@@ -1,0 +1,19 @@
+#!/bin/bash
+# Everything the round's DESIGN.md / README cite, regenerated on one box (GPU box only, ~12 min):
+#   gpurun --timeout 1200 -- 'bash tools/make_evidence.sh r03'       then copy gpurun_out/prof_final/* into profiles/
+set -o pipefail
+R=${1:-r03}
+cd "$GRAFT_REPO_ROOT" || exit 1
+bash tools/make_profiles.sh $R || exit 1
+OUT=gpurun_out/prof_final
+bash tools/prof_forced.sh $R || exit 1
+cp gpurun_out/prof_fc/${R}_forced_collectives_* $OUT/
+PPEA_FORCE_COLLECTIVES=1 python3 bench.py --no_cpu_baseline > $OUT/${R}_forced_collectives_n1.json 2> $OUT/fc.err || exit 1
+python3 bench.py --no_cpu_baseline --rep_size l --batch 8 > $OUT/${R}_bench_n1_config_l.json 2>> $OUT/cfg.err || exit 1
+python3 bench.py --no_cpu_baseline --dc --height 192 --width 512 --batch 4 > $OUT/${R}_bench_n1_config_dc192.json 2>> $OUT/cfg.err || exit 1
+python3 bench.py --no_cpu_baseline --dc --height 512 --width 1024 --batch 4 > $OUT/${R}_bench_n1_config_dc512.json 2>> $OUT/cfg.err || exit 1
+python3 bench.py --no_cpu_baseline --input_pipeline > $OUT/${R}_bench_n1_input_pipeline.json 2>> $OUT/cfg.err || exit 1
+python3 tools/render_parity.py > $OUT/${R}_bf16_render_parity.txt 2>> $OUT/cfg.err || exit 1
+python3 tools/dwconv_phases.py 2>/dev/null | grep -v amdgpu > $OUT/${R}_dwconv_phases.txt
+(cd tools && python3 bench_dwbn.py 2>/dev/null | grep -v amdgpu > ../$OUT/${R}_dwconv_fused_bn.txt)
+echo evidence done
