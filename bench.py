@@ -285,11 +285,11 @@ def main():
             e_ev.synchronize()
             t_pw = s_ev.elapsed_time(e_ev) / 20 * 1e-3
         flops = 2.0 * B * 480 * 512 * 2048
-        pw_roof = {"kernel": "pwconv_kernel<128,2,2,0,false,32>: 1x1 conv 512 -> 2048 on [%d,512,12,40] (ConvFFN pw1, stage 2)" % B,
+        pw_roof = {"kernel": "pwconv2_kernel<128,32,0>: 1x1 conv 512 -> 2048 on [%d,512,12,40] (ConvFFN pw1, stage 2)" % B,
                    "bound": "mfma", "achieved": round(flops / t_pw / 1e12, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                    "frac": round(flops / t_pw / 1e12 / MFMA_BF16_PEAK_TF, 4), "traffic": None,
                    "back_to_back_us": round(t_pw * 1e6, 1), "flops_per_launch": flops,
-                   "note": "host-paced launches: hipGraph-paced 23 us (profiles/r02_pwconv_shapes.txt); "
+                   "note": "host-paced launches; hipGraph-paced per trunk shape vs the library: profiles/r03_pwconv_shapes.txt; "
                            "algorithmic bytes %.1f MB" % ((B * 480 * (512 + 2048) + 512 * 2048) * 2 / 1e6)}
         del xx, aa
     barrier()

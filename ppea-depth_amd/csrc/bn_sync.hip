@@ -125,6 +125,8 @@ __global__ __launch_bounds__(256) void bn_sums_to_packed(const float* __restrict
     if (c >= C) return;
     const float2* p = reinterpret_cast<const float2*>(partial) + (long)c * P;
     double s = 0.0, q = 0.0;
+    // (unrolled: the loads of eight iterations are in flight together; the additions keep their order)
+#pragma unroll 8
     for (int i = lane; i < P; i += 64) {
         const float2 v = p[i];
         s += (double)v.x; q += (double)v.y;

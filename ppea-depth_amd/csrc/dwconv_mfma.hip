@@ -565,6 +565,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     if constexpr (BN) {
         const float2* sp = reinterpret_cast<const float2*>(bn.sums) + (long)c * bn.P;
         double ds = 0.0, dq = 0.0;
+#pragma unroll 8
         for (int i = lane; i < bn.P; i += 64) {
             const float2 v = sp[i];
             ds += (double)v.x; dq += (double)v.y;
