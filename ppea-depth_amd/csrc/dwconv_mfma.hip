@@ -65,34 +65,71 @@ struct Seg {
     static constexpr int STRIDE = lds_stride_bytes(WL);
 };
 
-// Packed filter image (built once per weight version by ppea_dwconv_lk_pack_bf16): the Toeplitz fragments themselves, in
-// REGISTER layout --
-//   img[c][ky][s][lane][0..7] bf16 = wpad[ky][i0 + j],  i0 = 32 + 32 s + 8 (lane >> 4) - (lane & 15) + (P - JOFF),
-//   wpad[ky][i] = w[ky][i - 32] for 0 <= i - 32 < K, else 0        (dgrad: both filter axes reversed)
-// -- so a wave fetches the B fragment of (ky, chunk s) with ONE coalesced 16-byte load per lane (1 KB per wave
-// instruction).  Round 1 / 2 kept a 4-shifted-copy source image (24 KB per channel) and gathered each fragment with two
-// 8-byte loads per lane at 2-byte-granular offsets: 134 poorly coalesced loads per lane at k = 31, measured at 12 % (stage 0)
-// to 30 % (stage 2) of a wave's time (tools/dwconv_phases.py).  The image is 62 KB per channel at k = 31; the waves of a
-// channel read the same bytes (L2).
+// Packed filter image (built once per weight version by ppea_dwconv_lk_pack_bf16): the filter itself, bf16
+//   img[c][ky * K + t] = w[c][ky][t]   (dgrad: both axes reversed),  padded to a multiple of 8 elements per channel
+// -- 1.9 KB per channel at k = 31.  The Toeplitz fragment of (filter row ky, chunk s) in register layout is
+//   frag[lane][0..7] = wpad[ky][i0 + j],  i0 = 32 + 32 s + 8 (lane >> 4) - (lane & 15) + (P - JOFF),
+//   wpad[ky][i] = w[ky][i - 32] for 0 <= i - 32 < K, else 0,
+// eight consecutive taps at a 2-byte-granular offset.  Every wave builds the K * NS (+ KS) fragments of its channel in its
+// prologue through its own (still unused) LDS tile region: the filter rows are written twice, zero-padded, the second copy
+// shifted by one element, so that every lane's window starts on a 4-byte boundary of one of the copies and a fragment is
+// two `ds_read2_b32`.  Round 1 / 2 gathered the fragments from a 4-shifted-copy image in global memory (134 poorly
+// coalesced loads per lane, 12-30 % of a wave's time); the first half of round 3 stored the fragments themselves (62 KB per
+// channel: ONE coalesced 16-byte load per fragment, but 30 MB of filter image per stage-2 launch against 18 MB of
+// activations -- 25 % of that kernel's time, tools/dwconv_phases.py).
 constexpr int frag_ns(int K) { return (16 + 2 * (K / 2) <= 32) ? 1 : 2; }
-constexpr int packed_elems(int K) { return K * frag_ns(K) * 64 * 8; }
+constexpr int packed_elems(int K) { return (K * K + 7) & ~7; }
+constexpr int FR_COPY_B = 192;                                  // one zero-padded filter row: 96 bf16
+constexpr int FR_ROW_B = 2 * FR_COPY_B;                         // + the copy shifted by one element
+constexpr int frag_scratch_bytes(int K, int KS) { return (K + KS) * FR_ROW_B; }
 
 template <int K, int NS>
-__device__ __forceinline__ bf16x8 load_bfrag(const uint16_t* __restrict__ img, int ky, int s, int lane) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + ((ky * NS + s) * 64 + lane) * 8));
+__device__ __forceinline__ void build_bfrags(bf16x8 (&bf)[K][NS], const uint16_t* __restrict__ img, uint8_t* scratch,
+                                             int lane) {
+    constexpr int P = K / 2, JOFF = (NS == 1) ? 8 : 16;
+    constexpr int PIECES = packed_elems(K) / 8, PL = (PIECES + 63) / 64;
+    static_assert(32 + 32 * (NS - 1) + 24 + (P - JOFF) + 8 <= 96 && 32 - 15 + (P - JOFF) >= 1, "window leaves the padded row");
+    uint4 v[PL];
+#pragma unroll
+    for (int u = 0; u < PL; ++u) {                              // unconditional loads (the last piece again for idle lanes)
+        const int p = min(lane + 64 * u, PIECES - 1);
+        v[u] = reinterpret_cast<const uint4*>(img)[p];
+    }
+    for (int off = lane * 16; off < K * FR_ROW_B; off += 64 * 16)
+        *reinterpret_cast<uint4*>(scratch + off) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < PL; ++u) {
+        const uint32_t wds[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = (lane + 64 * u) * 8 + q;
+            if (e < K * K) {
+                const int ky = e / K, t = e - ky * K;
+                const uint16_t val = (uint16_t)(wds[q >> 1] >> (16 * (q & 1)));
+                uint8_t* row = scratch + ky * FR_ROW_B;
+                *reinterpret_cast<uint16_t*>(row + 2 * (32 + t)) = val;
+                *reinterpret_cast<uint16_t*>(row + FR_COPY_B + 2 * (31 + t)) = val;
+            }
+        }
+    }
+    const int i0 = 32 + 8 * (lane >> 4) - (lane & 15) + (P - JOFF);
+    const uint8_t* base = scratch + ((i0 & 1) ? FR_COPY_B + 2 * (i0 - 1) : 2 * i0);
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(base + ky * FR_ROW_B + sidx * 64);
+            bf[ky][sidx] = __builtin_bit_cast(bf16x8, make_uint4(p[0], p[1], p[2], p[3]));
+        }
 }
 
 __global__ void pack_filter_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int C, int K, int flip) {
-    const int NS = frag_ns(K), P = K / 2, JOFF = NS == 1 ? 8 : 16;
-    const long total = (long)C * K * NS * 512;
+    const int PE = packed_elems(K);
+    const long total = (long)C * PE;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        const long r = i >> 9;                                   // (c * K + ky) * NS + s
-        const int sidx = (int)(r % NS), ky = (int)((r / NS) % K), c = (int)(r / ((long)NS * K));
-        const int t = 32 * sidx + 8 * (lane >> 4) - (lane & 15) + (P - JOFF) + j;      // tap index = i0 + j - 32
+        const int e = (int)(i % PE), c = (int)(i / PE);
         float v = 0.f;
-        if (t >= 0 && t < K)
-            v = flip ? w[((long)c * K + (K - 1 - ky)) * K + (K - 1 - t)] : w[((long)c * K + ky) * K + t];
+        if (e < K * K) v = flip ? w[(long)c * K * K + (K * K - 1 - e)] : w[(long)c * K * K + e];
         out[i] = __builtin_bit_cast(uint16_t, (__bf16)v);
     }
 }
@@ -535,18 +572,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     PROF_T(t_begin);
-    // The Toeplitz fragments come straight from the packed image in global memory (L2: the waves of a channel
-    // read the same bytes), already in register layout: one coalesced 16-byte load per fragment and lane, all
-    // issued before the first wait.
-    const uint16_t* wimg_b = w_big + (long)c * packed_elems(K);
-    const uint16_t* wimg_s = (KS > 0) ? w_small + (long)c * packed_elems(KS) : nullptr;
-
-    // Toeplitz fragments of the whole filter: registers for the rest of the kernel
+    // The Toeplitz fragments of the whole filter: built from the channel's filter through the wave's LDS region (see
+    // build_bfrags), registers for the rest of the kernel.  The region is the wave's own and LDS operations of one wave
+    // execute in order, so the staging writes further down need no wait.
+    uint8_t* tile0 = smem + (long)wave * region_bytes;
     bf16x8 bf_big[K][GE::NS];
-#pragma unroll
-    for (int ky = 0; ky < K; ++ky)
-#pragma unroll
-        for (int s = 0; s < GE::NS; ++s) bf_big[ky][s] = load_bfrag<K, GE::NS>(wimg_b, ky, s, lane);
+    build_bfrags<K, GE::NS>(bf_big, w_big + (long)c * packed_elems(K), tile0, lane);
     // Park most Toeplitz fragments in the accumulator half of the unified register file (MFMA reads its
     // B operand from AGPRs directly); this keeps the arch VGPRs free for A-fragment prefetch.
 #pragma unroll
@@ -555,10 +586,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
         for (int s = 0; s < GE::NS; ++s)
             if (ky * GE::NS + s >= AGPR_FROM) asm volatile("" : "+a"(bf_big[ky][s]));
     bf16x8 bf_small[(KS > 0 ? KS : 1)][1];
-    if constexpr (KS > 0) {
-#pragma unroll
-        for (int ky = 0; ky < KS; ++ky) bf_small[ky][0] = load_bfrag<KS, GS::NS>(wimg_s, ky, 0, lane);
-    }
+    if constexpr (KS > 0)
+        build_bfrags<KS, 1>(bf_small, w_small + (long)c * packed_elems(KS), tile0 + K * FR_ROW_B, lane);
 
     // fused input BatchNorm: this channel's statistics from the producer's partial sums (bn_finalize_sums' arithmetic)
     float bn_a = 1.f, bn_o = 0.f;
@@ -589,7 +618,6 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
         }
     }
 
-    uint8_t* tile0 = smem + (long)wave * region_bytes;
     uint8_t* tile1 = tile0 + tile_bytes;
     constexpr int SM_ROW0 = GE::P - GS::P;                  // small-kernel rows inside the big halo
     constexpr int SM_COLB = (GE::JOFF - GS::JOFF) * 2;      // byte offset of its first chunk
@@ -821,7 +849,8 @@ int launch(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const u
         for (; g >= 1; --g) {
             const int rows = (g > 1) ? g * (H + K - 1) : ((H < cand ? H : cand) + K - 1);
             const int tb = (rows * STRIDE_B + 15) & ~15;
-            const int reg = NT_IN * tb;
+            // (the region also hosts the prologue's fragment construction, see build_bfrags)
+            const int reg = NT_IN * tb > frag_scratch_bytes(K, KS) ? NT_IN * tb : frag_scratch_bytes(K, KS);
             if (WAVES * reg <= LDS_LIMIT) { band = cand; G = g; tile_bytes = tb; region = reg; break; }
         }
         if (band) break;

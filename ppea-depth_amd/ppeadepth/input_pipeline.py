@@ -12,7 +12,7 @@ draw per item shared by all its frames, `ToTensor`, and the per-scale intrinsics
 * ColorJitter is torchvision's PIL path (what the reference runs: PIL images through `transforms.ColorJitter`) restated
   on uint8 batches -- ImageEnhance blends, Pillow's RGB <-> HSV integer conversions, 8-bit quantisation after every
   operation, a fresh parameter draw for every frame and scale -- BIT-EXACT with Pillow (tests/test_host_cpu.py against
-  oracle/ref_jitter.py).
+  a Pillow-based restatement kept with the test infrastructure).
 """
 import math
 
