@@ -23,6 +23,7 @@
 // Replaces nn.Conv2d(groups=C) at networks/replknet_adapter.py:225-239 under bf16 autocast.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 
 #ifdef DW_PROF
@@ -154,6 +155,35 @@ struct BnIn {
     const float *gamma, *beta;
     float *running_mean, *running_var, *mean_out, *invstd_out;
 };
+
+// This channel's BatchNorm as y = a * x + o from the producer's partial sums (the arithmetic and order of bn_finalize_sums,
+// every lane of the wave gets the same values); `writer`: this wave stores the saved statistics and updates the running ones.
+__device__ __forceinline__ void bn_channel_affine(const BnIn& bn, int c, int lane, bool writer, float& a, float& o) {
+    const float2* sp = reinterpret_cast<const float2*>(bn.sums) + (long)c * bn.P;
+    double ds = 0.0, dq = 0.0;
+#pragma unroll 8
+    for (int i = lane; i < bn.P; i += 64) {
+        const float2 v = sp[i];
+        ds += (double)v.x; dq += (double)v.y;
+    }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) { ds += __shfl_xor(ds, k, WAVE); dq += __shfl_xor(dq, k, WAVE); }
+    const double mean = ds / (double)bn.count;
+    double var = dq / (double)bn.count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float invstd = rsqrtf((float)var + bn.eps);
+    a = bn.gamma[c] * invstd;
+    o = bn.beta[c] - (float)mean * a;
+    if (lane == 0 && writer) {                                   // one writer per channel
+        bn.mean_out[c] = (float)mean;
+        bn.invstd_out[c] = invstd;
+        if (bn.running_mean != nullptr) {
+            const float unbiased = (float)(var * (double)bn.count / fmax((double)bn.count - 1.0, 1.0));
+            bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * (float)mean;
+            bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * unbiased;
+        }
+    }
+}
 
 __device__ __forceinline__ uint32_t bnrelu2(uint32_t v, float a, float o) {
     const float lo = fmaxf(a * __uint_as_float(v << 16) + o, 0.f), hi = fmaxf(a * __uint_as_float(v & 0xffff0000u) + o, 0.f);
@@ -589,34 +619,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
     if constexpr (KS > 0)
         build_bfrags<KS, 1>(bf_small, w_small + (long)c * packed_elems(KS), tile0 + K * FR_ROW_B, lane);
 
+    PROF_T(t_frags);
+    PROF_ADD(6, t_begin, t_frags);
     // fused input BatchNorm: this channel's statistics from the producer's partial sums (bn_finalize_sums' arithmetic)
     float bn_a = 1.f, bn_o = 0.f;
-    if constexpr (BN) {
-        const float2* sp = reinterpret_cast<const float2*>(bn.sums) + (long)c * bn.P;
-        double ds = 0.0, dq = 0.0;
-#pragma unroll 8
-        for (int i = lane; i < bn.P; i += 64) {
-            const float2 v = sp[i];
-            ds += (double)v.x; dq += (double)v.y;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, WAVE); dq += __shfl_xor(dq, o, WAVE); }
-        const double mean = ds / (double)bn.count;
-        double var = dq / (double)bn.count - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float invstd = rsqrtf((float)var + bn.eps);
-        bn_a = bn.gamma[c] * invstd;
-        bn_o = bn.beta[c] - (float)mean * bn_a;
-        if (lane == 0 && wid == (long)c * wpc) {                 // one writer per channel
-            bn.mean_out[c] = (float)mean;
-            bn.invstd_out[c] = invstd;
-            if (bn.running_mean != nullptr) {
-                const float unbiased = (float)(var * (double)bn.count / fmax((double)bn.count - 1.0, 1.0));
-                bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * (float)mean;
-                bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * unbiased;
-            }
-        }
-    }
+    if constexpr (BN) bn_channel_affine(bn, c, lane, wid == (long)c * wpc, bn_a, bn_o);
 
     uint8_t* tile1 = tile0 + tile_bytes;
     constexpr int SM_ROW0 = GE::P - GS::P;                  // small-kernel rows inside the big halo
@@ -831,6 +838,280 @@ __global__ __launch_bounds__(64 * WAVES, 1) void dwconv_mfma_kernel(
 #endif
 }
 
+// ---- batch-major variant for small planes (stages 2 / 3: 12 x 40 and 6 x 20 maps) ----------------------------------------
+// On a plane that is shorter than the filter the row-band formulation above wastes most of its work: G planes stacked along
+// M carry K - 1 zero halo rows each (12 image rows in 38 LDS rows at k = 27), 56 % of the MFMAs multiply zeros, every MFMA
+// needs its own A window from LDS (the stream is LDS-bound), and a channel's 3 items do not divide by its 2 waves.  Here
+// the M dimension of the MFMA is the BATCH instead: for one channel, one input row y_in and one 32-column chunk, the A
+// fragment is [16 images x 32 input columns]; multiplied by the Toeplitz fragment of filter row ky = y_in - y_out + P it
+// contributes to output row y_out of all 16 images at once.  A wave owns NY output rows (NY accumulators per column tile,
+// + NY for the 5x5 branch) and walks y_in: ONE A read serves up to NY MFMAs, only (y_in, y_out) pairs inside the plane are
+// issued, and a wave needs only the filter rows with |y_in - y_out| <= P that its rows can meet (17 of 27 at H = 12).
+// k = 27 on [12,512,12,40]: 522 MFMAs and 108 LDS reads per wave instead of 1 062 / 1 062 on the slower wave.
+// The H / NY waves of a channel share its staged tile  [y_in][image][columns]  (row stride as above: conflict-free b128 reads
+// for 16 images x 4 k-groups); a workgroup is 4 waves = 4 NY / H channels, one group of up to 16 images.
+template <int K, int NTX>
+struct BmGeo {
+    static constexpr int WL = 16 * (NTX - 1) + 32 * Geo<K>::NS;
+    static constexpr int STRIDE = lds_stride_bytes(WL);
+    static constexpr int CG = WL / 8;
+};
+
+// Stage the channel's rows: piece (y, image, VEC-element column group) -> tile[(y * nimg + image) * STRIDE + 2 VEC * group];
+// `sub` / `nsub`: this lane's index among the lanes that share the tile.  VEC = 8 (16-byte pieces) needs W % 8 == 0,
+// VEC = 4 (8-byte pieces: the 6 x 20 maps) W % 4 == 0 -- a piece is wholly inside the plane or wholly padding.
+template <int K, int NTX, int H, bool BN, int VEC>
+__device__ __forceinline__ void stage_bm(uint8_t* tile, const uint16_t* __restrict__ src, int n0, int nimg, int C, int c,
+                                         int W, int sub, int nsub, float bn_a, float bn_o) {
+    using B = BmGeo<K, NTX>;
+    using V = std::conditional_t<VEC == 8, uint4, uint2>;
+    constexpr int U = 8, CGV = B::WL / VEC;
+    const int total = H * nimg * CGV;
+    for (int i0 = sub; i0 < total; i0 += nsub * U) {
+        V v[U];
+        int dst[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = i0 + u * nsub;
+            const int pc = idx % CGV, rn = idx / CGV, y = rn / nimg, n = rn - y * nimg;
+            const int gx = VEC * pc - Geo<K>::JOFF;
+            ok[u] = idx < total && gx >= 0 && gx + VEC <= W;
+            dst[u] = idx < total ? rn * B::STRIDE + pc * (2 * VEC) : -1;
+            v[u] = *reinterpret_cast<const V*>(ok[u] ? src + (((long)(n0 + n) * C + c) * H + y) * W + gx : src);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (dst[u] >= 0) {
+                if constexpr (VEC == 8) {
+                    const uint4 t = bn_piece<BN>(v[u], bn_a, bn_o);
+                    *reinterpret_cast<uint4*>(tile + dst[u]) =
+                        make_uint4(ok[u] ? t.x : 0u, ok[u] ? t.y : 0u, ok[u] ? t.z : 0u, ok[u] ? t.w : 0u);
+                } else {
+                    uint2 t = v[u];
+                    if constexpr (BN) t = make_uint2(bnrelu2(t.x, bn_a, bn_o), bnrelu2(t.y, bn_a, bn_o));
+                    *reinterpret_cast<uint2*>(tile + dst[u]) = make_uint2(ok[u] ? t.x : 0u, ok[u] ? t.y : 0u);
+                }
+            }
+        }
+    }
+}
+
+template <int OFF>
+__device__ __forceinline__ void ds_read128_at(bf16x8& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+
+template <int K, int KS, int MODE, int H, int NY, int Y0>
+struct BmSched {
+    static constexpr int P = K / 2, PS = (KS > 0 ? KS : 1) / 2;
+    static constexpr int YLO = Y0 - P > 0 ? Y0 - P : 0;
+    static constexpr int YHI = Y0 + NY - 1 + P < H - 1 ? Y0 + NY - 1 + P + 1 : H;       // exclusive
+    static constexpr bool SHARE = MODE == 0 && Geo<K>::JOFF == Geo<(KS > 0 ? KS : 5)>::JOFF;   // small chunk == big chunk 0
+    static constexpr bool small_at(int yi) { return KS > 0 && yi >= Y0 - PS && yi <= Y0 + NY - 1 + PS; }
+    static constexpr int reads_at(int yi) { return Geo<K>::NS + ((small_at(yi) && !SHARE) ? 1 : 0); }
+};
+
+template <int K, int KS, int MODE, int H, int NY, int Y0, int YI>
+__device__ __forceinline__ void bm_issue(bf16x8 (&slot)[3], uint32_t a_big, uint32_t a_small, int ystride) {
+    using S = BmSched<K, KS, MODE, H, NY, Y0>;
+    if constexpr (YI < S::YHI) {
+        const uint32_t ab = a_big + (uint32_t)(YI * ystride);
+        ds_read128_at<0>(slot[0], ab);
+        if constexpr (Geo<K>::NS == 2) ds_read128_at<64>(slot[1], ab);
+        if constexpr (S::small_at(YI) && !S::SHARE) ds_read128_at<0>(slot[2], a_small + (uint32_t)(YI * ystride));
+    }
+}
+
+// One input row: issue the next row's reads, wait for this row's, then every (output row, chunk) MFMA it feeds.
+template <int K, int KS, int MODE, int H, int NY, int Y0, int YI>
+__device__ __forceinline__ void bm_row(f32x4 (&accb)[NY], f32x4 (&accs)[NY], bf16x8 (&ring)[2][3], uint32_t a_big,
+                                       uint32_t a_small, int ystride, const bf16x8 (&bfb)[K][Geo<K>::NS],
+                                       const bf16x8 (&bfs)[(KS > 0 ? KS : 1)][1]) {
+    using S = BmSched<K, KS, MODE, H, NY, Y0>;
+    constexpr int NS = Geo<K>::NS;
+    if constexpr (YI < S::YHI) {
+        constexpr int cur = (YI - S::YLO) & 1;
+        bm_issue<K, KS, MODE, H, NY, Y0, YI + 1>(ring[cur ^ 1], a_big, a_small, ystride);
+        constexpr int younger = (YI + 1 < S::YHI) ? S::reads_at(YI + 1) : 0;
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(ring[cur][0]), "+v"(ring[cur][1]), "+v"(ring[cur][2]) : "i"(younger));
+#pragma unroll
+        for (int sidx = 0; sidx < NS; ++sidx)
+#pragma unroll
+            for (int j = 0; j < NY; ++j) {
+                const int d = YI - (Y0 + j);
+                if (d >= -S::P && d <= S::P)
+                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfb[d + S::P][sidx], ring[cur][sidx], accb[j], 0, 0, 0);
+            }
+        if constexpr (S::small_at(YI)) {
+#pragma unroll
+            for (int j = 0; j < NY; ++j) {
+                const int d = YI - (Y0 + j);
+                if (d >= -S::PS && d <= S::PS) {
+                    const bf16x8& a = S::SHARE ? ring[cur][0] : ring[cur][2];
+                    if constexpr (MODE == 0) accs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfs[d + S::PS][0], a, accs[j], 0, 0, 0);
+                    else accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfs[d + S::PS][0], a, accb[j], 0, 0, 0);
+                }
+            }
+        }
+        bm_row<K, KS, MODE, H, NY, Y0, YI + 1>(accb, accs, ring, a_big, a_small, ystride, bfb, bfs);
+    }
+}
+
+template <int K, int KS, int MODE, int H, int NY, int NTX, int Y0>
+__device__ __forceinline__ void bm_rows(uint32_t a_big, uint32_t a_small, int ystride, const bf16x8 (&bfb)[K][Geo<K>::NS],
+                                        const bf16x8 (&bfs)[(KS > 0 ? KS : 1)][1], uint16_t* __restrict__ out0,
+                                        uint16_t* __restrict__ out1, long plane_off, bool img_ok, int W, int lane,
+                                        bool want_stats, float (&st)[4]) {
+    using S = BmSched<K, KS, MODE, H, NY, Y0>;
+#pragma unroll 1
+    for (int ct = 0; ct < NTX; ++ct) {
+        if (16 * ct >= W) break;
+        f32x4 accb[NY], accs[NY];
+#pragma unroll
+        for (int j = 0; j < NY; ++j) { accb[j] = {0.f, 0.f, 0.f, 0.f}; accs[j] = {0.f, 0.f, 0.f, 0.f}; }
+        bf16x8 ring[2][3];
+        const uint32_t ab = a_big + 32 * ct, as = a_small + 32 * ct;
+        bm_issue<K, KS, MODE, H, NY, Y0, S::YLO>(ring[0], ab, as, ystride);
+        bm_row<K, KS, MODE, H, NY, Y0, S::YLO>(accb, accs, ring, ab, as, ystride, bfb, bfs);
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+            const RowOffs ro{img_ok ? (int)(plane_off + (long)(Y0 + j) * W) : -1};
+            store_tile(out0, accb[j], ro, W, 16 * ct, lane);
+            if constexpr (MODE == 0 && KS > 0) store_tile(out1, accs[j], ro, W, 16 * ct, lane);
+            if constexpr (MODE == 0) {
+                if (want_stats) {
+                    tile_stats(accb[j], ro, W, 16 * ct, lane, st[0], st[1]);
+                    if constexpr (KS > 0) tile_stats(accs[j], ro, W, 16 * ct, lane, st[2], st[3]);
+                }
+            }
+        }
+    }
+}
+
+template <int K, int KS, int MODE, int H, int NY, int NTX, bool BN>
+__global__ __launch_bounds__(256, 1) void dwconv_bm_kernel(
+    const uint16_t* __restrict__ in0, const uint16_t* __restrict__ in1, const uint16_t* __restrict__ w_big,
+    const uint16_t* __restrict__ w_small, uint16_t* __restrict__ out0, uint16_t* __restrict__ out1, int N, int C, int W,
+    int gi, int ngroups, int tile_bytes, float* __restrict__ stats, BnIn bn) {
+    static_assert(!BN || MODE == 0, "the fused input BatchNorm is a forward feature");
+    static_assert(H % NY == 0 && 4 % (H / NY) == 0, "a workgroup holds whole channels");
+    using GE = Geo<K>;
+    using GS = Geo<(KS > 0 ? KS : 5)>;
+    using B = BmGeo<K, NTX>;
+    constexpr int SPLIT = H / NY, CPW = 4 / SPLIT;
+    constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int cb = blockIdx.x / ngroups, grp = blockIdx.x - cb * ngroups;
+    const int cw = cb * CPW + wave / SPLIT, part = wave % SPLIT;
+    const bool active = cw < C;                                 // idle waves still meet the barriers
+    const int c = active ? cw : C - 1;
+    const int n0 = grp * gi, nimg = min(gi, N - n0);
+
+    bf16x8 bf_big[K][GE::NS];
+    uint8_t* scratch = smem + wave * frag_scratch_bytes(K, KS);
+    build_bfrags<K, GE::NS>(bf_big, w_big + (long)c * packed_elems(K), scratch, lane);
+    bf16x8 bf_small[(KS > 0 ? KS : 1)][1];
+    if constexpr (KS > 0) build_bfrags<KS, 1>(bf_small, w_small + (long)c * packed_elems(KS), scratch + K * FR_ROW_B, lane);
+    float bn_a = 1.f, bn_o = 0.f;
+    if constexpr (BN) bn_channel_affine(bn, c, lane, active && part == 0 && grp == 0, bn_a, bn_o);
+    __syncthreads();                                             // every wave's fragments are in registers: the scratch is free
+
+    uint8_t* tile0 = smem + (wave / SPLIT) * (NT_IN * tile_bytes);
+    if ((W & 7) == 0) {
+        stage_bm<K, NTX, H, BN, 8>(tile0, in0, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, bn_a, bn_o);
+        if constexpr (NT_IN == 2) stage_bm<K, NTX, H, false, 8>(tile0 + tile_bytes, in1, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, 1.f, 0.f);
+    } else {
+        stage_bm<K, NTX, H, BN, 4>(tile0, in0, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, bn_a, bn_o);
+        if constexpr (NT_IN == 2) stage_bm<K, NTX, H, false, 4>(tile0 + tile_bytes, in1, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, 1.f, 0.f);
+    }
+    __syncthreads();
+    if (!active) return;
+
+    // this lane's A row = image (lane & 15), clamped: the rows past the group's last image repeat it and are never stored
+    const int n = min(lane & 15, nimg - 1);
+    const uint32_t a_big = lds_addr(tile0) + (uint32_t)(n * B::STRIDE + 16 * (lane >> 4));
+    const uint32_t a_small = lds_addr(tile0 + (MODE == 1 ? tile_bytes : 0)) + (uint32_t)(n * B::STRIDE + 16 * (lane >> 4)) +
+                             (GE::JOFF - GS::JOFF) * 2;
+    const int ystride = nimg * B::STRIDE;
+    const bool img_ok = (lane & 15) < nimg;
+    const long plane_off = ((long)(n0 + n) * C + c) * (long)H * W;
+    float st[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool want_stats = stats != nullptr;
+#define PPEA_BM_PART(P_)                                                                                               \
+    if constexpr (P_ < SPLIT) {                                                                                         \
+        if (part == P_)                                                                                                 \
+            bm_rows<K, KS, MODE, H, NY, NTX, P_ * NY>(a_big, a_small, ystride, bf_big, bf_small, out0, out1, plane_off,  \
+                                                      img_ok, W, lane, want_stats, st);                                 \
+    }
+    PPEA_BM_PART(0) PPEA_BM_PART(1) PPEA_BM_PART(2) PPEA_BM_PART(3)
+#undef PPEA_BM_PART
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (MODE == 0) {
+        if (want_stats) {                                        // stats [2][C][wpc][2], wpc = SPLIT * ngroups
+            const float sb = wave_sum(st[0]), qb = wave_sum(st[1]), ss = wave_sum(st[2]), qs = wave_sum(st[3]);
+            if (lane == 0) {
+                const int wpc = SPLIT * ngroups;
+                const long e = ((long)c * wpc + grp * SPLIT + part) * 2;
+                stats[e] = sb; stats[e + 1] = qb;
+                if constexpr (KS > 0) { stats[(long)C * wpc * 2 + e] = ss; stats[(long)C * wpc * 2 + e + 1] = qs; }
+            }
+        }
+    }
+}
+
+// returns PPEA_ERR_UNSUPPORTED when the shape is not this variant's (the caller falls back to the row-band kernel)
+template <int K, int KS, int MODE, int H, int NY, int NTX, bool BN>
+int launch_bm(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0, uint16_t* o1,
+              int N, int C, int W, hipStream_t st, float* stats, int* wpc_out, const BnIn* bn) {
+    using B = BmGeo<K, NTX>;
+    constexpr int SPLIT = H / NY, CPW = 4 / SPLIT;
+    constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
+    if ((long)N * C * H * W >= (1L << 31) || (long)N * C * H * W < 8) return PPEA_ERR_UNSUPPORTED;   // (masked pieces read the tensor's first 16 bytes)
+    int gi = 0, tile_bytes = 0;
+    for (int cand : {16, 12, 8, 4}) {                            // images per group: the largest whose tiles fit
+        const int alloc = N < cand ? N : cand;
+        const int tb = H * alloc * B::STRIDE;
+        if (CPW * NT_IN * tb <= LDS_LIMIT) { gi = cand; tile_bytes = tb; break; }
+    }
+    if (!gi) return PPEA_ERR_UNSUPPORTED;
+    const int ngroups = (N + gi - 1) / gi;
+    if (wpc_out != nullptr) { *wpc_out = SPLIT * ngroups; return 0; }
+    size_t lds = (size_t)CPW * NT_IN * tile_bytes;
+    if (lds < (size_t)4 * frag_scratch_bytes(K, KS)) lds = (size_t)4 * frag_scratch_bytes(K, KS);
+    auto kern = dwconv_bm_kernel<K, KS, MODE, H, NY, NTX, BN>;
+    const BnIn bnv = bn != nullptr ? *bn : BnIn{nullptr, 0, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(((C + CPW - 1) / CPW) * ngroups)), dim3(256), lds, st, in0, in1, wb, ws, o0, o1,
+                       N, C, W, gi, ngroups, tile_bytes, stats, bnv);
+    return launch_status();
+}
+
+template <int K, int KS, int MODE, int H, int NY>
+int launch_bm_w(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0, uint16_t* o1,
+                int N, int C, int W, hipStream_t st, float* stats, int* wpc_out, const BnIn* bn) {
+    static const bool on = !(getenv("PPEA_DW_BM") != nullptr && getenv("PPEA_DW_BM")[0] == '0');
+    if (!on || (W & 3) != 0 || W > 48) return PPEA_ERR_UNSUPPORTED;
+    const int ntx = (W + 15) / 16;
+#define PPEA_BM_NTX(NTX_)                                                                                              \
+    if (ntx == NTX_) {                                                                                                  \
+        if constexpr (MODE == 0) {                                                                                      \
+            if (bn != nullptr) return launch_bm<K, KS, MODE, H, NY, NTX_, true>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, bn);  \
+        }                                                                                                               \
+        if (bn != nullptr) return PPEA_ERR_UNSUPPORTED;                                                                 \
+        return launch_bm<K, KS, MODE, H, NY, NTX_, false>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, nullptr);  \
+    }
+    PPEA_BM_NTX(1) PPEA_BM_NTX(2) PPEA_BM_NTX(3)
+#undef PPEA_BM_NTX
+    return PPEA_ERR_UNSUPPORTED;
+}
+
 // stats / wpc_out: forward only -- per-wave partial sums for the BatchNorm pair (see the kernel); wpc_out != nullptr:
 // do not launch, return the number of waves per channel (= partials per channel) the launch would use
 template <int K, int KS, int MODE, int NSEG, bool BN = false, bool WS = false>
@@ -896,6 +1177,13 @@ inline long staged_cols(int W, int nseg) {
 template <int K, int KS, int MODE>
 int launch_k(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0,
              uint16_t* o1, int N, int C, int H, int W, hipStream_t st, float* stats, int* wpc_out, const BnIn* bn) {
+    if constexpr (KS == 5 && (K == 27 || K == 13)) {             // small planes: the batch-major variant
+        constexpr int HB = K == 27 ? 12 : 6;
+        if (H == HB) {
+            const int err = launch_bm_w<K, KS, MODE, HB, 6>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, bn);
+            if (err != PPEA_ERR_UNSUPPORTED) return err;
+        }
+    }
     const long c5 = staged_cols<K>(W, 5), c3 = staged_cols<K>(W, 3), c2 = staged_cols<K>(W, 2);
     const int nseg = (c5 <= c3 && c5 <= c2) ? 5 : (c3 <= c2 ? 3 : 2);
     if constexpr (K == 31 && KS == 5) {

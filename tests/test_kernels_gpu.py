@@ -85,7 +85,11 @@ def test_dwconv_golden_reference(device, golden):
                                        (13, 2, 64, 2, 3), (27, 2, 32, 4, 6), (29, 2, 16, 8, 12), (31, 2, 8, 16, 24),
                                        (31, 2, 3, 48, 128), (29, 2, 3, 24, 64), (27, 3, 3, 12, 32), (13, 3, 3, 6, 16),
                                        (31, 2, 2, 70, 37), (27, 1, 2, 33, 90), (13, 2, 2, 17, 9), (31, 1, 1, 1, 1),
-                                       (31, 2, 2, 128, 256)])
+                                       (31, 2, 2, 128, 256),
+                                       # the batch-major variant (12 x W / 6 x W planes): full and ragged image groups, an
+                                       # odd channel count (idle wave), 1 / 2 / 3 column tiles, W % 8 == 4
+                                       (27, 12, 6, 12, 40), (27, 17, 2, 12, 40), (27, 20, 3, 12, 8), (27, 1, 1, 12, 24),
+                                       (13, 12, 8, 6, 20), (13, 18, 5, 6, 16), (13, 33, 2, 6, 44)])
 def test_dwconv_bf16_mfma(device, K, N, C, H, W):
     """bf16 I/O on the matrix cores (banded-Toeplitz MFMA kernel): bf16 activations and bf16-rounded
     filters (what autocast feeds a conv), fp32 accumulation, one bf16 rounding of the output."""
@@ -137,7 +141,10 @@ def test_dwconv_linearity_full_size(device):
 @pytest.mark.parametrize("N,C,H,W,K", [(12, 128, 48, 160, 31),       # config 2: RepLKNet-31B stage 0, batch 12
                                        (8, 192, 48, 160, 31),        # config 4: RepLKNet-31L stage 0, batch 8
                                        (8, 384, 24, 80, 29),         # config 4: stage 1
-                                       (2, 128, 128, 256, 31)])      # config 5: 512x1024 frames, stage 0
+                                       (2, 128, 128, 256, 31),       # config 5: 512x1024 frames, stage 0
+                                       (12, 512, 12, 40, 27),        # config 2: stage 2 (batch-major variant)
+                                       (8, 768, 12, 40, 27),         # config 4: stage 2
+                                       (12, 1024, 6, 20, 13)])       # config 2: stage 3
 def test_dwconv_bf16_mfma_full_size_vs_fp32_kernel(device, N, C, H, W, K):
     """The BENCHMARKED kernel at the benchmarked shapes of configs 2, 4 and 5: bf16 through `dwconv_mfma_kernel<K,5,*,*>`
     (forward and data gradient) against the fp32 vector kernel `dwconv_lk_kernel` on the same bf16-rounded values.
@@ -1061,7 +1068,8 @@ def test_pwconv_epilogue_sums_give_the_batchnorm_statistics(device, shape):
     assert rel_err(rm.cpu(), rm_ref.cpu()) < 1e-5 and rel_err(rv.cpu(), rv_ref.cpu()) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(12, 128, 48, 160, 31), (12, 256, 24, 80, 29), (3, 64, 20, 36, 13)])
+@pytest.mark.parametrize("shape", [(12, 128, 48, 160, 31), (12, 256, 24, 80, 29), (3, 64, 20, 36, 13), (12, 512, 12, 40, 27),
+                                   (20, 6, 6, 20, 13)])
 def test_dwconv_epilogue_sums_give_both_batchnorm_statistics(device, shape):
     """The large-kernel depthwise conv's epilogue returns per-channel partial sums of BOTH outputs (k x k and 5 x 5 branch,
     rka.py:232-239): same output bytes as the plain launch, and statistics of the stored bf16 tensors to 1e-6 / 1e-5."""
@@ -1273,7 +1281,7 @@ def test_decoder_adapter_split_equals_the_concatenated_form(device):
 
 
 @pytest.mark.parametrize("N,C,H,W,K", [(12, 128, 48, 160, 31), (12, 256, 24, 80, 29), (12, 512, 12, 40, 27),
-                                       (6, 1024, 6, 20, 13), (3, 64, 20, 36, 13), (2, 64, 50, 37, 31)])
+                                       (6, 1024, 6, 20, 13), (3, 64, 20, 36, 13), (2, 64, 50, 37, 31), (17, 64, 12, 32, 27)])
 def test_dwconv_fused_input_batchnorm_relu_equals_the_separate_launches(device, N, C, H, W, K):
     """RepLKBlock forward (rka.py:305-308): pw1's BatchNorm + ReLU applied inside the depthwise kernel's staging pass
     (statistics finalised per wave from the 1x1 conv's epilogue sums) against the separate launches -- statistics from the

@@ -34,7 +34,7 @@ for (K, C, H, W) in [(31, 128, 48, 160), (29, 256, 24, 80), (27, 512, 12, 40), (
     act = buf[buf[:, 5] > 0].astype(np.float64)
     m = act.mean(0)
     names = ["setup (filter image + fragments)", "staging per wave (all items)", "mac streams", "epilogues (cvt + stores)",
-             "items total", "kernel total"]
+             "items total", "kernel total", "  of setup: fragment construction"]
     print(f"k{K} [{N},{C},{H},{W}]: {len(act)} waves; shader-clock cycles per wave (s_memtime):")
     for i, nm in enumerate(names):
         print(f"   {nm:36s} {m[i]:10.0f} cycles   ({100 * m[i] / m[5]:5.1f} % of the wave)")
