@@ -913,26 +913,26 @@ struct BmSched {
 };
 
 template <int K, int KS, int MODE, int H, int NY, int Y0, int YI>
-__device__ __forceinline__ void bm_issue(bf16x8 (&slot)[3], uint32_t a_big, uint32_t a_small, int ystride) {
+__device__ __forceinline__ void bm_issue(bf16x8 (&slot)[3], uint32_t a_big, uint32_t a_small, int ystride, int ystride_s) {
     using S = BmSched<K, KS, MODE, H, NY, Y0>;
     if constexpr (YI < S::YHI) {
         const uint32_t ab = a_big + (uint32_t)(YI * ystride);
         ds_read128_at<0>(slot[0], ab);
         if constexpr (Geo<K>::NS == 2) ds_read128_at<64>(slot[1], ab);
-        if constexpr (S::small_at(YI) && !S::SHARE) ds_read128_at<0>(slot[2], a_small + (uint32_t)(YI * ystride));
+        if constexpr (S::small_at(YI) && !S::SHARE) ds_read128_at<0>(slot[2], a_small + (uint32_t)(YI * ystride_s));
     }
 }
 
 // One input row: issue the next row's reads, wait for this row's, then every (output row, chunk) MFMA it feeds.
 template <int K, int KS, int MODE, int H, int NY, int Y0, int YI>
 __device__ __forceinline__ void bm_row(f32x4 (&accb)[NY], f32x4 (&accs)[NY], bf16x8 (&ring)[2][3], uint32_t a_big,
-                                       uint32_t a_small, int ystride, const bf16x8 (&bfb)[K][Geo<K>::NS],
+                                       uint32_t a_small, int ystride, int ystride_s, const bf16x8 (&bfb)[K][Geo<K>::NS],
                                        const bf16x8 (&bfs)[(KS > 0 ? KS : 1)][1]) {
     using S = BmSched<K, KS, MODE, H, NY, Y0>;
     constexpr int NS = Geo<K>::NS;
     if constexpr (YI < S::YHI) {
         constexpr int cur = (YI - S::YLO) & 1;
-        bm_issue<K, KS, MODE, H, NY, Y0, YI + 1>(ring[cur ^ 1], a_big, a_small, ystride);
+        bm_issue<K, KS, MODE, H, NY, Y0, YI + 1>(ring[cur ^ 1], a_big, a_small, ystride, ystride_s);
         constexpr int younger = (YI + 1 < S::YHI) ? S::reads_at(YI + 1) : 0;
         asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(ring[cur][0]), "+v"(ring[cur][1]), "+v"(ring[cur][2]) : "i"(younger));
 #pragma unroll
@@ -954,12 +954,13 @@ __device__ __forceinline__ void bm_row(f32x4 (&accb)[NY], f32x4 (&accs)[NY], bf1
                 }
             }
         }
-        bm_row<K, KS, MODE, H, NY, Y0, YI + 1>(accb, accs, ring, a_big, a_small, ystride, bfb, bfs);
+        bm_row<K, KS, MODE, H, NY, Y0, YI + 1>(accb, accs, ring, a_big, a_small, ystride, ystride_s, bfb, bfs);
     }
 }
 
 template <int K, int KS, int MODE, int H, int NY, int NTX, int Y0>
-__device__ __forceinline__ void bm_rows(uint32_t a_big, uint32_t a_small, int ystride, const bf16x8 (&bfb)[K][Geo<K>::NS],
+__device__ __forceinline__ void bm_rows(uint32_t a_big, uint32_t a_small, int ystride, int ystride_s,
+                                        const bf16x8 (&bfb)[K][Geo<K>::NS],
                                         const bf16x8 (&bfs)[(KS > 0 ? KS : 1)][1], uint16_t* __restrict__ out0,
                                         uint16_t* __restrict__ out1, long plane_off, bool img_ok, int W, int lane,
                                         bool want_stats, float (&st)[4]) {
@@ -972,8 +973,8 @@ __device__ __forceinline__ void bm_rows(uint32_t a_big, uint32_t a_small, int ys
         for (int j = 0; j < NY; ++j) { accb[j] = {0.f, 0.f, 0.f, 0.f}; accs[j] = {0.f, 0.f, 0.f, 0.f}; }
         bf16x8 ring[2][3];
         const uint32_t ab = a_big + 32 * ct, as = a_small + 32 * ct;
-        bm_issue<K, KS, MODE, H, NY, Y0, S::YLO>(ring[0], ab, as, ystride);
-        bm_row<K, KS, MODE, H, NY, Y0, S::YLO>(accb, accs, ring, ab, as, ystride, bfb, bfs);
+        bm_issue<K, KS, MODE, H, NY, Y0, S::YLO>(ring[0], ab, as, ystride, ystride_s);
+        bm_row<K, KS, MODE, H, NY, Y0, S::YLO>(accb, accs, ring, ab, as, ystride, ystride_s, bfb, bfs);
 #pragma unroll
         for (int j = 0; j < NY; ++j) {
             const RowOffs ro{img_ok ? (int)(plane_off + (long)(Y0 + j) * W) : -1};
@@ -993,7 +994,7 @@ template <int K, int KS, int MODE, int H, int NY, int NTX, bool BN>
 __global__ __launch_bounds__(256, 1) void dwconv_bm_kernel(
     const uint16_t* __restrict__ in0, const uint16_t* __restrict__ in1, const uint16_t* __restrict__ w_big,
     const uint16_t* __restrict__ w_small, uint16_t* __restrict__ out0, uint16_t* __restrict__ out1, int N, int C, int W,
-    int gi, int ngroups, int tile_bytes, float* __restrict__ stats, BnIn bn) {
+    int gi, int ngroups, int tile_bytes, int tile1_bytes, float* __restrict__ stats, BnIn bn) {
     static_assert(!BN || MODE == 0, "the fused input BatchNorm is a forward feature");
     static_assert(H % NY == 0 && 4 % (H / NY) == 0, "a workgroup holds whole channels");
     using GE = Geo<K>;
@@ -1019,13 +1020,15 @@ __global__ __launch_bounds__(256, 1) void dwconv_bm_kernel(
     if constexpr (BN) bn_channel_affine(bn, c, lane, active && part == 0 && grp == 0, bn_a, bn_o);
     __syncthreads();                                             // every wave's fragments are in registers: the scratch is free
 
-    uint8_t* tile0 = smem + (wave / SPLIT) * (NT_IN * tile_bytes);
+    // dgrad: the second input (the 5x5 branch's gradient) is staged with the 5x5 kernel's own, narrower column geometry
+    using B1 = BmGeo<(KS > 0 ? KS : 5), NTX>;
+    uint8_t* tile0 = smem + (wave / SPLIT) * (tile_bytes + (NT_IN == 2 ? tile1_bytes : 0));
     if ((W & 7) == 0) {
         stage_bm<K, NTX, H, BN, 8>(tile0, in0, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, bn_a, bn_o);
-        if constexpr (NT_IN == 2) stage_bm<K, NTX, H, false, 8>(tile0 + tile_bytes, in1, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, 1.f, 0.f);
+        if constexpr (NT_IN == 2) stage_bm<(KS > 0 ? KS : 5), NTX, H, false, 8>(tile0 + tile_bytes, in1, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, 1.f, 0.f);
     } else {
         stage_bm<K, NTX, H, BN, 4>(tile0, in0, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, bn_a, bn_o);
-        if constexpr (NT_IN == 2) stage_bm<K, NTX, H, false, 4>(tile0 + tile_bytes, in1, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, 1.f, 0.f);
+        if constexpr (NT_IN == 2) stage_bm<(KS > 0 ? KS : 5), NTX, H, false, 4>(tile0 + tile_bytes, in1, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, 1.f, 0.f);
     }
     __syncthreads();
     if (!active) return;
@@ -1033,9 +1036,9 @@ __global__ __launch_bounds__(256, 1) void dwconv_bm_kernel(
     // this lane's A row = image (lane & 15), clamped: the rows past the group's last image repeat it and are never stored
     const int n = min(lane & 15, nimg - 1);
     const uint32_t a_big = lds_addr(tile0) + (uint32_t)(n * B::STRIDE + 16 * (lane >> 4));
-    const uint32_t a_small = lds_addr(tile0 + (MODE == 1 ? tile_bytes : 0)) + (uint32_t)(n * B::STRIDE + 16 * (lane >> 4)) +
-                             (GE::JOFF - GS::JOFF) * 2;
-    const int ystride = nimg * B::STRIDE;
+    const uint32_t a_small = MODE == 1 ? lds_addr(tile0 + tile_bytes) + (uint32_t)(n * B1::STRIDE + 16 * (lane >> 4))
+                                       : a_big + (GE::JOFF - GS::JOFF) * 2;
+    const int ystride = nimg * B::STRIDE, ystride_s = MODE == 1 ? nimg * B1::STRIDE : ystride;
     const bool img_ok = (lane & 15) < nimg;
     const long plane_off = ((long)(n0 + n) * C + c) * (long)H * W;
     float st[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1043,7 +1046,7 @@ __global__ __launch_bounds__(256, 1) void dwconv_bm_kernel(
 #define PPEA_BM_PART(P_)                                                                                               \
     if constexpr (P_ < SPLIT) {                                                                                         \
         if (part == P_)                                                                                                 \
-            bm_rows<K, KS, MODE, H, NY, NTX, P_ * NY>(a_big, a_small, ystride, bf_big, bf_small, out0, out1, plane_off,  \
+            bm_rows<K, KS, MODE, H, NY, NTX, P_ * NY>(a_big, a_small, ystride, ystride_s, bf_big, bf_small, out0, out1, plane_off,  \
                                                       img_ok, W, lane, want_stats, st);                                 \
     }
     PPEA_BM_PART(0) PPEA_BM_PART(1) PPEA_BM_PART(2) PPEA_BM_PART(3)
@@ -1070,16 +1073,17 @@ int launch_bm(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, cons
     constexpr int SPLIT = H / NY, CPW = 4 / SPLIT;
     constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
     if ((long)N * C * H * W >= (1L << 31) || (long)N * C * H * W < 8) return PPEA_ERR_UNSUPPORTED;   // (masked pieces read the tensor's first 16 bytes)
-    int gi = 0, tile_bytes = 0;
+    using B1 = BmGeo<(KS > 0 ? KS : 5), NTX>;
+    int gi = 0, tile_bytes = 0, tile1_bytes = 0;
     for (int cand : {16, 12, 8, 4}) {                            // images per group: the largest whose tiles fit
         const int alloc = N < cand ? N : cand;
-        const int tb = H * alloc * B::STRIDE;
-        if (CPW * NT_IN * tb <= LDS_LIMIT) { gi = cand; tile_bytes = tb; break; }
+        const int tb = H * alloc * B::STRIDE, tb1 = NT_IN == 2 ? H * alloc * B1::STRIDE : 0;
+        if (CPW * (tb + tb1) <= LDS_LIMIT) { gi = cand; tile_bytes = tb; tile1_bytes = tb1; break; }
     }
     if (!gi) return PPEA_ERR_UNSUPPORTED;
     const int ngroups = (N + gi - 1) / gi;
     if (wpc_out != nullptr) { *wpc_out = SPLIT * ngroups; return 0; }
-    size_t lds = (size_t)CPW * NT_IN * tile_bytes;
+    size_t lds = (size_t)CPW * (tile_bytes + tile1_bytes);
     if (lds < (size_t)4 * frag_scratch_bytes(K, KS)) lds = (size_t)4 * frag_scratch_bytes(K, KS);
     auto kern = dwconv_bm_kernel<K, KS, MODE, H, NY, NTX, BN>;
     const BnIn bnv = bn != nullptr ? *bn : BnIn{nullptr, 0, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1089,25 +1093,32 @@ int launch_bm(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, cons
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(((C + CPW - 1) / CPW) * ngroups)), dim3(256), lds, st, in0, in1, wb, ws, o0, o1,
-                       N, C, W, gi, ngroups, tile_bytes, stats, bnv);
+                       N, C, W, gi, ngroups, tile_bytes, tile1_bytes, stats, bnv);
     return launch_status();
 }
 
-template <int K, int KS, int MODE, int H, int NY>
-int launch_bm_w(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0, uint16_t* o1,
+template <int K, int KS, int MODE, int H, int NY, int NTX>
+int launch_bm_n(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0, uint16_t* o1,
                 int N, int C, int W, hipStream_t st, float* stats, int* wpc_out, const BnIn* bn) {
-    static const bool on = !(getenv("PPEA_DW_BM") != nullptr && getenv("PPEA_DW_BM")[0] == '0');
-    if (!on || (W & 3) != 0 || W > 48) return PPEA_ERR_UNSUPPORTED;
-    const int ntx = (W + 15) / 16;
-#define PPEA_BM_NTX(NTX_)                                                                                              \
-    if (ntx == NTX_) {                                                                                                  \
-        if constexpr (MODE == 0) {                                                                                      \
-            if (bn != nullptr) return launch_bm<K, KS, MODE, H, NY, NTX_, true>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, bn);  \
-        }                                                                                                               \
-        if (bn != nullptr) return PPEA_ERR_UNSUPPORTED;                                                                 \
-        return launch_bm<K, KS, MODE, H, NY, NTX_, false>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, nullptr);  \
+    if constexpr (MODE == 0) {
+        if (bn != nullptr) return launch_bm<K, KS, MODE, H, NY, NTX, true>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, bn);
     }
-    PPEA_BM_NTX(1) PPEA_BM_NTX(2) PPEA_BM_NTX(3)
+    if (bn != nullptr) return PPEA_ERR_UNSUPPORTED;
+    return launch_bm<K, KS, MODE, H, NY, NTX, false>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, nullptr);
+}
+
+// The plane sizes this variant is built for: RepLKNet stages 1-3 of 192-row frames (24 x {64, 80}, 12 x {8..48}, 6 x {4..48}).
+template <int K, int KS, int MODE>
+int launch_bm_w(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0, uint16_t* o1,
+                int N, int C, int H, int W, hipStream_t st, float* stats, int* wpc_out, const BnIn* bn) {
+    static const bool on = !(getenv("PPEA_DW_BM") != nullptr && getenv("PPEA_DW_BM")[0] == '0');
+    if (!on || (W & 3) != 0) return PPEA_ERR_UNSUPPORTED;
+    const int ntx = (W + 15) / 16;
+#define PPEA_BM_NTX(H_, NTX_)                                                                                          \
+    if (H == H_ && ntx == NTX_) return launch_bm_n<K, KS, MODE, H_, 6, NTX_>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, bn);
+    if constexpr (KS == 5 && K == 29) { PPEA_BM_NTX(24, 4) PPEA_BM_NTX(24, 5) }
+    if constexpr (KS == 5 && K == 27) { PPEA_BM_NTX(12, 1) PPEA_BM_NTX(12, 2) PPEA_BM_NTX(12, 3) }
+    if constexpr (KS == 5 && K == 13) { PPEA_BM_NTX(6, 1) PPEA_BM_NTX(6, 2) PPEA_BM_NTX(6, 3) }
 #undef PPEA_BM_NTX
     return PPEA_ERR_UNSUPPORTED;
 }
@@ -1177,12 +1188,9 @@ inline long staged_cols(int W, int nseg) {
 template <int K, int KS, int MODE>
 int launch_k(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0,
              uint16_t* o1, int N, int C, int H, int W, hipStream_t st, float* stats, int* wpc_out, const BnIn* bn) {
-    if constexpr (KS == 5 && (K == 27 || K == 13)) {             // small planes: the batch-major variant
-        constexpr int HB = K == 27 ? 12 : 6;
-        if (H == HB) {
-            const int err = launch_bm_w<K, KS, MODE, HB, 6>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, bn);
-            if (err != PPEA_ERR_UNSUPPORTED) return err;
-        }
+    {                                                            // small planes: the batch-major variant
+        const int err = launch_bm_w<K, KS, MODE>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out, bn);
+        if (err != PPEA_ERR_UNSUPPORTED) return err;
     }
     const long c5 = staged_cols<K>(W, 5), c3 = staged_cols<K>(W, 3), c2 = staged_cols<K>(W, 2);
     const int nseg = (c5 <= c3 && c5 <= c2) ? 5 : (c3 <= c2 ? 3 : 2);
