@@ -858,42 +858,69 @@ struct BmGeo {
 };
 
 // Stage the channel's rows: piece (y, image, VEC-element column group) -> tile[(y * nimg + image) * STRIDE + 2 VEC * group];
-// `sub` / `nsub`: this lane's index among the lanes that share the tile.  VEC = 8 (16-byte pieces) needs W % 8 == 0,
+// x0: first output column of the staged segment; `sub` / `nsub`: this lane's index among the lanes that share the tile.  VEC = 8 (16-byte pieces) needs W % 8 == 0,
 // VEC = 4 (8-byte pieces: the 6 x 20 maps) W % 4 == 0 -- a piece is wholly inside the plane or wholly padding.
-template <int K, int NTX, int H, bool BN, int VEC>
-__device__ __forceinline__ void stage_bm(uint8_t* tile, const uint16_t* __restrict__ src, int n0, int nimg, int C, int c,
-                                         int W, int sub, int nsub, float bn_a, float bn_o) {
+template <int K, int NTX, int H, int VEC, int CPW_>
+struct BmStage {
     using B = BmGeo<K, NTX>;
     using V = std::conditional_t<VEC == 8, uint4, uint2>;
-    constexpr int U = 8, CGV = B::WL / VEC;
-    const int total = H * nimg * CGV;
-    for (int i0 = sub; i0 < total; i0 += nsub * U) {
-        V v[U];
-        int dst[U];
-        bool ok[U];
+    // pieces in (image, row, column group) order: consecutive lanes walk a plane's rows (contiguous in memory), and the
+    // decode divides by constants only; U pieces in flight per lane before the first LDS store (2 round trips on the
+    // 48 x 160 maps, one on the small ones)
+    static constexpr int CGV = B::WL / VEC;
+    static constexpr int PPL = (H * 12 * CGV + 64 * (4 / CPW_) - 1) / (64 * (4 / CPW_));   // pieces per lane at 12 images
+    static constexpr int U = PPL <= 14 ? PPL : (PPL + 1) / 2;
+
+    __device__ static __forceinline__ void load(V (&v)[U], const uint16_t* __restrict__ src, int n0, int nimg, int C, int c,
+                                                int W, int x0, int i0, int nsub) {
+        const int total = H * nimg * CGV;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int idx = i0 + u * nsub;
-            const int pc = idx % CGV, rn = idx / CGV, y = rn / nimg, n = rn - y * nimg;
-            const int gx = VEC * pc - Geo<K>::JOFF;
-            ok[u] = idx < total && gx >= 0 && gx + VEC <= W;
-            dst[u] = idx < total ? rn * B::STRIDE + pc * (2 * VEC) : -1;
-            v[u] = *reinterpret_cast<const V*>(ok[u] ? src + (((long)(n0 + n) * C + c) * H + y) * W + gx : src);
+            const int pc = idx % CGV, r2 = idx / CGV, y = r2 % H, n = r2 / H;
+            const int gx = x0 + VEC * pc - Geo<K>::JOFF;
+            const bool ok = idx < total && gx >= 0 && gx + VEC <= W;
+            v[u] = *reinterpret_cast<const V*>(ok ? src + (((long)(n0 + n) * C + c) * H + y) * W + gx : src);
         }
+    }
+    template <bool BN>
+    __device__ static __forceinline__ void store(const V (&v)[U], uint8_t* tile, int nimg, int W, int x0, int i0, int nsub,
+                                                 float bn_a, float bn_o) {
+        const int total = H * nimg * CGV;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (dst[u] >= 0) {
+            const int idx = i0 + u * nsub;
+            const int pc = idx % CGV, r2 = idx / CGV, y = r2 % H, n = r2 / H;
+            const int gx = x0 + VEC * pc - Geo<K>::JOFF;
+            const bool ok = gx >= 0 && gx + VEC <= W;
+            if (idx < total) {
+                uint8_t* dst = tile + (y * nimg + n) * B::STRIDE + pc * (2 * VEC);
                 if constexpr (VEC == 8) {
                     const uint4 t = bn_piece<BN>(v[u], bn_a, bn_o);
-                    *reinterpret_cast<uint4*>(tile + dst[u]) =
-                        make_uint4(ok[u] ? t.x : 0u, ok[u] ? t.y : 0u, ok[u] ? t.z : 0u, ok[u] ? t.w : 0u);
+                    *reinterpret_cast<uint4*>(dst) = make_uint4(ok ? t.x : 0u, ok ? t.y : 0u, ok ? t.z : 0u, ok ? t.w : 0u);
                 } else {
                     uint2 t = v[u];
                     if constexpr (BN) t = make_uint2(bnrelu2(t.x, bn_a, bn_o), bnrelu2(t.y, bn_a, bn_o));
-                    *reinterpret_cast<uint2*>(tile + dst[u]) = make_uint2(ok[u] ? t.x : 0u, ok[u] ? t.y : 0u);
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(ok ? t.x : 0u, ok ? t.y : 0u);
                 }
             }
         }
+    }
+};
+
+// Stage the channel's rows: piece (y, image, VEC-element column group) -> tile[(y * nimg + image) * STRIDE + 2 VEC * group];
+// x0: first output column of the staged segment; `sub` / `nsub`: this lane's index among the lanes that share the tile.
+// VEC = 8 (16-byte pieces) needs W % 8 == 0, VEC = 4 (8-byte pieces: the 6 x 20 maps) W % 4 == 0 -- a piece is wholly inside
+// the plane or wholly padding.
+template <int K, int NTX, int H, bool BN, int VEC, int CPW_>
+__device__ __forceinline__ void stage_bm(uint8_t* tile, const uint16_t* __restrict__ src, int n0, int nimg, int C, int c,
+                                         int W, int x0, int sub, int nsub, float bn_a, float bn_o) {
+    using St = BmStage<K, NTX, H, VEC, CPW_>;
+    const int total = H * nimg * St::CGV;
+    for (int i0 = sub; i0 < total; i0 += nsub * St::U) {
+        typename St::V v[St::U];
+        St::load(v, src, n0, nimg, C, c, W, x0, i0, nsub);
+        St::template store<BN>(v, tile, nimg, W, x0, i0, nsub, bn_a, bn_o);
     }
 }
 
@@ -902,51 +929,68 @@ __device__ __forceinline__ void ds_read128_at(bf16x8& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
 }
 
-template <int K, int KS, int MODE, int H, int NY, int Y0>
+// The rows of one wave: Y0 + RS * j, j < NY (RS = 1: a contiguous block; RS = number of waves: interleaved, which gives
+// every wave the same number of in-plane (y_in, y_out) pairs on planes taller than the filter's half width).
+template <int K, int KS, int MODE, int H, int NY, int Y0, int RS>
 struct BmSched {
     static constexpr int P = K / 2, PS = (KS > 0 ? KS : 1) / 2;
+    static constexpr int YLAST = Y0 + RS * (NY - 1);
     static constexpr int YLO = Y0 - P > 0 ? Y0 - P : 0;
-    static constexpr int YHI = Y0 + NY - 1 + P < H - 1 ? Y0 + NY - 1 + P + 1 : H;       // exclusive
+    static constexpr int YHI = YLAST + P < H - 1 ? YLAST + P + 1 : H;                     // exclusive
     static constexpr bool SHARE = MODE == 0 && Geo<K>::JOFF == Geo<(KS > 0 ? KS : 5)>::JOFF;   // small chunk == big chunk 0
-    static constexpr bool small_at(int yi) { return KS > 0 && yi >= Y0 - PS && yi <= Y0 + NY - 1 + PS; }
+    static constexpr bool small_at(int yi) {
+        if (KS == 0) return false;
+        for (int j = 0; j < NY; ++j) {
+            const int d = yi - (Y0 + RS * j);
+            if (d >= -PS && d <= PS) return true;
+        }
+        return false;
+    }
     static constexpr int reads_at(int yi) { return Geo<K>::NS + ((small_at(yi) && !SHARE) ? 1 : 0); }
 };
 
-template <int K, int KS, int MODE, int H, int NY, int Y0, int YI>
-__device__ __forceinline__ void bm_issue(bf16x8 (&slot)[3], uint32_t a_big, uint32_t a_small, int ystride, int ystride_s) {
-    using S = BmSched<K, KS, MODE, H, NY, Y0>;
+// ra_big / ra_small: LDS addresses of THIS lane's pieces of tile row YI (the caller steps them row by row: an address that
+// is a*YI + b with a run-time stride would be hoisted out of the column-tile loop for all rows at once -- 2 x 48 live values).
+template <int K, int KS, int MODE, int H, int NY, int Y0, int RS, int YI>
+__device__ __forceinline__ void bm_issue(bf16x8 (&slot)[3], uint32_t ra_big, uint32_t ra_small) {
+    using S = BmSched<K, KS, MODE, H, NY, Y0, RS>;
     if constexpr (YI < S::YHI) {
-        const uint32_t ab = a_big + (uint32_t)(YI * ystride);
-        ds_read128_at<0>(slot[0], ab);
-        if constexpr (Geo<K>::NS == 2) ds_read128_at<64>(slot[1], ab);
-        if constexpr (S::small_at(YI) && !S::SHARE) ds_read128_at<0>(slot[2], a_small + (uint32_t)(YI * ystride_s));
+        ds_read128_at<0>(slot[0], ra_big);
+        if constexpr (Geo<K>::NS == 2) ds_read128_at<64>(slot[1], ra_big);
+        if constexpr (S::small_at(YI) && !S::SHARE) ds_read128_at<0>(slot[2], ra_small);
     }
 }
 
+__device__ __forceinline__ void bm_next_row(uint32_t& ra, int stride) {          // opaque to the optimiser on purpose
+    asm volatile("v_add_u32 %0, %0, %1" : "+v"(ra) : "s"(stride));
+}
+
 // One input row: issue the next row's reads, wait for this row's, then every (output row, chunk) MFMA it feeds.
-template <int K, int KS, int MODE, int H, int NY, int Y0, int YI>
-__device__ __forceinline__ void bm_row(f32x4 (&accb)[NY], f32x4 (&accs)[NY], bf16x8 (&ring)[2][3], uint32_t a_big,
-                                       uint32_t a_small, int ystride, int ystride_s, const bf16x8 (&bfb)[K][Geo<K>::NS],
+template <int K, int KS, int MODE, int H, int NY, int Y0, int RS, int YI>
+__device__ __forceinline__ void bm_row(f32x4 (&accb)[NY], f32x4 (&accs)[NY], bf16x8 (&ring)[2][3], uint32_t ra_big,
+                                       uint32_t ra_small, int ystride, int ystride_s, const bf16x8 (&bfb)[K][Geo<K>::NS],
                                        const bf16x8 (&bfs)[(KS > 0 ? KS : 1)][1]) {
-    using S = BmSched<K, KS, MODE, H, NY, Y0>;
+    using S = BmSched<K, KS, MODE, H, NY, Y0, RS>;
     constexpr int NS = Geo<K>::NS;
     if constexpr (YI < S::YHI) {
         constexpr int cur = (YI - S::YLO) & 1;
-        bm_issue<K, KS, MODE, H, NY, Y0, YI + 1>(ring[cur ^ 1], a_big, a_small, ystride, ystride_s);
+        bm_next_row(ra_big, ystride);
+        if constexpr (KS > 0 && !S::SHARE) bm_next_row(ra_small, ystride_s);
+        bm_issue<K, KS, MODE, H, NY, Y0, RS, YI + 1>(ring[cur ^ 1], ra_big, ra_small);
         constexpr int younger = (YI + 1 < S::YHI) ? S::reads_at(YI + 1) : 0;
         asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(ring[cur][0]), "+v"(ring[cur][1]), "+v"(ring[cur][2]) : "i"(younger));
 #pragma unroll
         for (int sidx = 0; sidx < NS; ++sidx)
 #pragma unroll
             for (int j = 0; j < NY; ++j) {
-                const int d = YI - (Y0 + j);
+                const int d = YI - (Y0 + RS * j);
                 if (d >= -S::P && d <= S::P)
                     accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfb[d + S::P][sidx], ring[cur][sidx], accb[j], 0, 0, 0);
             }
         if constexpr (S::small_at(YI)) {
 #pragma unroll
             for (int j = 0; j < NY; ++j) {
-                const int d = YI - (Y0 + j);
+                const int d = YI - (Y0 + RS * j);
                 if (d >= -S::PS && d <= S::PS) {
                     const bf16x8& a = S::SHARE ? ring[cur][0] : ring[cur][2];
                     if constexpr (MODE == 0) accs[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfs[d + S::PS][0], a, accs[j], 0, 0, 0);
@@ -954,49 +998,78 @@ __device__ __forceinline__ void bm_row(f32x4 (&accb)[NY], f32x4 (&accs)[NY], bf1
                 }
             }
         }
-        bm_row<K, KS, MODE, H, NY, Y0, YI + 1>(accb, accs, ring, a_big, a_small, ystride, ystride_s, bfb, bfs);
+        bm_row<K, KS, MODE, H, NY, Y0, RS, YI + 1>(accb, accs, ring, ra_big, ra_small, ystride, ystride_s, bfb, bfs);
     }
 }
 
-template <int K, int KS, int MODE, int H, int NY, int NTX, int Y0>
+// The `nct` column tiles of the staged segment (first output column x0) for this wave's rows.
+// Epilogue: W % 4 == 0 and tiles start at multiples of 16, so a lane's four columns are inside the plane together and its
+// 8-byte store is aligned -- one validity test per column tile, then per output row two conversions, one pointer step and
+// one store (store_tile's general form re-derives all of that per row: ~200 cycles per row and output, as much time as the
+// MFMA rows themselves on the 12 x 40 maps).
+template <int K, int KS, int MODE, int H, int NY, int Y0, int RS>
 __device__ __forceinline__ void bm_rows(uint32_t a_big, uint32_t a_small, int ystride, int ystride_s,
                                         const bf16x8 (&bfb)[K][Geo<K>::NS],
                                         const bf16x8 (&bfs)[(KS > 0 ? KS : 1)][1], uint16_t* __restrict__ out0,
-                                        uint16_t* __restrict__ out1, long plane_off, bool img_ok, int W, int lane,
-                                        bool want_stats, float (&st)[4]) {
-    using S = BmSched<K, KS, MODE, H, NY, Y0>;
+                                        uint16_t* __restrict__ out1, long plane_off, bool img_ok, int W, int x0, int nct,
+                                        int lane, bool want_stats, float (&st)[4], unsigned long long* prof = nullptr) {
+    using S = BmSched<K, KS, MODE, H, NY, Y0, RS>;
 #pragma unroll 1
-    for (int ct = 0; ct < NTX; ++ct) {
-        if (16 * ct >= W) break;
+    for (int ct = 0; ct < nct; ++ct) {
+        PROF_T(t_ct0);
         f32x4 accb[NY], accs[NY];
 #pragma unroll
         for (int j = 0; j < NY; ++j) { accb[j] = {0.f, 0.f, 0.f, 0.f}; accs[j] = {0.f, 0.f, 0.f, 0.f}; }
         bf16x8 ring[2][3];
-        const uint32_t ab = a_big + 32 * ct, as = a_small + 32 * ct;
-        bm_issue<K, KS, MODE, H, NY, Y0, S::YLO>(ring[0], ab, as, ystride, ystride_s);
-        bm_row<K, KS, MODE, H, NY, Y0, S::YLO>(accb, accs, ring, ab, as, ystride, ystride_s, bfb, bfs);
+        const uint32_t ab = a_big + 32 * ct + S::YLO * ystride, as = a_small + 32 * ct + S::YLO * ystride_s;
+        bm_issue<K, KS, MODE, H, NY, Y0, RS, S::YLO>(ring[0], ab, as);
+        bm_row<K, KS, MODE, H, NY, Y0, RS, S::YLO>(accb, accs, ring, ab, as, ystride, ystride_s, bfb, bfs);
+        PROF_T(t_ct1);
+        PROF_ADD(3, t_ct0, t_ct1);
+        // the addresses are derived HERE, after the MFMA rows (opaque copy): hoisted above them they would be live across
+        // the rows, spilled, and every reload's vmcnt wait would drain the epilogue's own stores
+        int col = x0 + 16 * ct + 4 * (lane >> 4);
+        asm volatile("" : "+v"(col));
+        if (img_ok && col < W) {
+            const long first = plane_off + (long)Y0 * W + col;
+            uint16_t* p0 = out0 + first;
+            uint16_t* p1 = (MODE == 0 && KS > 0) ? out1 + first : nullptr;
+            const int step = RS * W;
 #pragma unroll
-        for (int j = 0; j < NY; ++j) {
-            const RowOffs ro{img_ok ? (int)(plane_off + (long)(Y0 + j) * W) : -1};
-            store_tile(out0, accb[j], ro, W, 16 * ct, lane);
-            if constexpr (MODE == 0 && KS > 0) store_tile(out1, accs[j], ro, W, 16 * ct, lane);
-            if constexpr (MODE == 0) {
-                if (want_stats) {
-                    tile_stats(accb[j], ro, W, 16 * ct, lane, st[0], st[1]);
-                    if constexpr (KS > 0) tile_stats(accs[j], ro, W, 16 * ct, lane, st[2], st[3]);
+            for (int j = 0; j < NY; ++j) {
+                *reinterpret_cast<uint2*>(p0) = make_uint2(pack_bf16x2(accb[j][0], accb[j][1]), pack_bf16x2(accb[j][2], accb[j][3]));
+                p0 += step;
+                if constexpr (MODE == 0 && KS > 0) {
+                    *reinterpret_cast<uint2*>(p1) = make_uint2(pack_bf16x2(accs[j][0], accs[j][1]), pack_bf16x2(accs[j][2], accs[j][3]));
+                    p1 += step;
+                }
+            }
+        }
+        if constexpr (MODE == 0) {
+            if (want_stats) {
+                const int po = img_ok ? (int)plane_off : -1;
+#pragma unroll
+                for (int j = 0; j < NY; ++j) {
+                    const RowOffs ro{po >= 0 ? po + (Y0 + RS * j) * W : -1};
+                    tile_stats(accb[j], ro, W, x0 + 16 * ct, lane, st[0], st[1]);
+                    if constexpr (KS > 0) tile_stats(accs[j], ro, W, x0 + 16 * ct, lane, st[2], st[3]);
                 }
             }
         }
     }
 }
 
-template <int K, int KS, int MODE, int H, int NY, int NTX, bool BN>
+// NTX: column tiles per staged segment; a workgroup walks `cpw` column tiles of its channel(s) from tile index wgi * cpw in
+// segments of NTX (one segment covers the plane on the small maps; the 48 x 160 maps are cut into 2 workgroups x (3 + 2)
+// tiles per channel).  RS: see BmSched.
+template <int K, int KS, int MODE, int H, int NY, int NTX, int RS, bool BN>
 __global__ __launch_bounds__(256, 1) void dwconv_bm_kernel(
     const uint16_t* __restrict__ in0, const uint16_t* __restrict__ in1, const uint16_t* __restrict__ w_big,
     const uint16_t* __restrict__ w_small, uint16_t* __restrict__ out0, uint16_t* __restrict__ out1, int N, int C, int W,
-    int gi, int ngroups, int tile_bytes, int tile1_bytes, float* __restrict__ stats, BnIn bn) {
+    int gi, int ngroups, int wgpc, int cpw, int tile_bytes, int tile1_bytes, float* __restrict__ stats, BnIn bn) {
     static_assert(!BN || MODE == 0, "the fused input BatchNorm is a forward feature");
     static_assert(H % NY == 0 && 4 % (H / NY) == 0, "a workgroup holds whole channels");
+    static_assert(RS == 1 || RS == H / NY, "rows of a wave: contiguous or interleaved over the channel's waves");
     using GE = Geo<K>;
     using GS = Geo<(KS > 0 ? KS : 5)>;
     using B = BmGeo<K, NTX>;
@@ -1005,11 +1078,18 @@ __global__ __launch_bounds__(256, 1) void dwconv_bm_kernel(
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int cb = blockIdx.x / ngroups, grp = blockIdx.x - cb * ngroups;
+    int bid = blockIdx.x;
+    const int wgi = bid % wgpc; bid /= wgpc;
+    const int grp = bid % ngroups;
+    const int cb = bid / ngroups;
     const int cw = cb * CPW + wave / SPLIT, part = wave % SPLIT;
     const bool active = cw < C;                                 // idle waves still meet the barriers
     const int c = active ? cw : C - 1;
     const int n0 = grp * gi, nimg = min(gi, N - n0);
+#ifdef DW_PROF
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    PROF_T(t_begin);
 
     bf16x8 bf_big[K][GE::NS];
     uint8_t* scratch = smem + wave * frag_scratch_bytes(K, KS);
@@ -1017,22 +1097,11 @@ __global__ __launch_bounds__(256, 1) void dwconv_bm_kernel(
     bf16x8 bf_small[(KS > 0 ? KS : 1)][1];
     if constexpr (KS > 0) build_bfrags<KS, 1>(bf_small, w_small + (long)c * packed_elems(KS), scratch + K * FR_ROW_B, lane);
     float bn_a = 1.f, bn_o = 0.f;
-    if constexpr (BN) bn_channel_affine(bn, c, lane, active && part == 0 && grp == 0, bn_a, bn_o);
-    __syncthreads();                                             // every wave's fragments are in registers: the scratch is free
+    if constexpr (BN) bn_channel_affine(bn, c, lane, active && part == 0 && grp == 0 && wgi == 0, bn_a, bn_o);
 
     // dgrad: the second input (the 5x5 branch's gradient) is staged with the 5x5 kernel's own, narrower column geometry
     using B1 = BmGeo<(KS > 0 ? KS : 5), NTX>;
     uint8_t* tile0 = smem + (wave / SPLIT) * (tile_bytes + (NT_IN == 2 ? tile1_bytes : 0));
-    if ((W & 7) == 0) {
-        stage_bm<K, NTX, H, BN, 8>(tile0, in0, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, bn_a, bn_o);
-        if constexpr (NT_IN == 2) stage_bm<(KS > 0 ? KS : 5), NTX, H, false, 8>(tile0 + tile_bytes, in1, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, 1.f, 0.f);
-    } else {
-        stage_bm<K, NTX, H, BN, 4>(tile0, in0, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, bn_a, bn_o);
-        if constexpr (NT_IN == 2) stage_bm<(KS > 0 ? KS : 5), NTX, H, false, 4>(tile0 + tile_bytes, in1, n0, nimg, C, c, W, part * 64 + lane, SPLIT * 64, 1.f, 0.f);
-    }
-    __syncthreads();
-    if (!active) return;
-
     // this lane's A row = image (lane & 15), clamped: the rows past the group's last image repeat it and are never stored
     const int n = min(lane & 15, nimg - 1);
     const uint32_t a_big = lds_addr(tile0) + (uint32_t)(n * B::STRIDE + 16 * (lane >> 4));
@@ -1043,21 +1112,59 @@ __global__ __launch_bounds__(256, 1) void dwconv_bm_kernel(
     const long plane_off = ((long)(n0 + n) * C + c) * (long)H * W;
     float st[4] = {0.f, 0.f, 0.f, 0.f};
     const bool want_stats = stats != nullptr;
+#ifdef DW_PROF
+#define PPEA_BM_PROF prof
+#else
+#define PPEA_BM_PROF nullptr
+#endif
+    const int ct_end = min((W + 15) / 16, (wgi + 1) * cpw);
+    PROF_T(t_setup_done);
+    PROF_ADD(0, t_begin, t_setup_done);
+    for (int cs = wgi * cpw; cs < ct_end; cs += NTX) {
+        PROF_T(t_seg);
+        // first pass: every wave's fragments are in registers and the scratch is free; later: the segment's reads are done
+        __syncthreads();
+        const int x0 = 16 * cs;
+        if ((W & 7) == 0) {
+            stage_bm<K, NTX, H, BN, 8, CPW>(tile0, in0, n0, nimg, C, c, W, x0, part * 64 + lane, SPLIT * 64, bn_a, bn_o);
+            if constexpr (NT_IN == 2) stage_bm<(KS > 0 ? KS : 5), NTX, H, false, 8, CPW>(tile0 + tile_bytes, in1, n0, nimg, C, c, W, x0, part * 64 + lane, SPLIT * 64, 1.f, 0.f);
+        } else {
+            stage_bm<K, NTX, H, BN, 4, CPW>(tile0, in0, n0, nimg, C, c, W, x0, part * 64 + lane, SPLIT * 64, bn_a, bn_o);
+            if constexpr (NT_IN == 2) stage_bm<(KS > 0 ? KS : 5), NTX, H, false, 4, CPW>(tile0 + tile_bytes, in1, n0, nimg, C, c, W, x0, part * 64 + lane, SPLIT * 64, 1.f, 0.f);
+        }
+        __syncthreads();
+        PROF_T(t_staged);
+        PROF_ADD(1, t_seg, t_staged);
+        const int nct = min(NTX, ct_end - cs);
+        if (active) {
 #define PPEA_BM_PART(P_)                                                                                               \
-    if constexpr (P_ < SPLIT) {                                                                                         \
-        if (part == P_)                                                                                                 \
-            bm_rows<K, KS, MODE, H, NY, NTX, P_ * NY>(a_big, a_small, ystride, ystride_s, bf_big, bf_small, out0, out1, plane_off,  \
-                                                      img_ok, W, lane, want_stats, st);                                 \
-    }
-    PPEA_BM_PART(0) PPEA_BM_PART(1) PPEA_BM_PART(2) PPEA_BM_PART(3)
+            if constexpr (P_ < SPLIT) {                                                                                 \
+                if (part == P_)                                                                                         \
+                    bm_rows<K, KS, MODE, H, NY, (RS == 1 ? P_ * NY : P_), RS>(a_big, a_small, ystride, ystride_s, bf_big, bf_small, out0, \
+                                                                             out1, plane_off, img_ok, W, x0, nct, lane, want_stats, st, PPEA_BM_PROF); \
+            }
+            PPEA_BM_PART(0) PPEA_BM_PART(1) PPEA_BM_PART(2) PPEA_BM_PART(3)
 #undef PPEA_BM_PART
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PROF_T(t_mac);
+        PROF_ADD(2, t_staged, t_mac);
+    }
+#ifdef DW_PROF
+    PROF_T(t_end);
+    prof[5] = t_end - t_begin;
+    {
+        const long wid = (long)blockIdx.x * 4 + wave;
+        if (lane == 0 && wid < 4096)
+            for (int i = 0; i < 8; ++i) g_dw_prof[wid][i] = prof[i];
+    }
+#endif
     if constexpr (MODE == 0) {
-        if (want_stats) {                                        // stats [2][C][wpc][2], wpc = SPLIT * ngroups
+        if (want_stats && active) {                              // stats [2][C][wpc][2], wpc = SPLIT * ngroups * wgpc
             const float sb = wave_sum(st[0]), qb = wave_sum(st[1]), ss = wave_sum(st[2]), qs = wave_sum(st[3]);
             if (lane == 0) {
-                const int wpc = SPLIT * ngroups;
-                const long e = ((long)c * wpc + grp * SPLIT + part) * 2;
+                const int wpc = SPLIT * ngroups * wgpc;
+                const long e = ((long)c * wpc + (grp * wgpc + wgi) * SPLIT + part) * 2;
                 stats[e] = sb; stats[e + 1] = qb;
                 if constexpr (KS > 0) { stats[(long)C * wpc * 2 + e] = ss; stats[(long)C * wpc * 2 + e + 1] = qs; }
             }
@@ -1066,14 +1173,14 @@ __global__ __launch_bounds__(256, 1) void dwconv_bm_kernel(
 }
 
 // returns PPEA_ERR_UNSUPPORTED when the shape is not this variant's (the caller falls back to the row-band kernel)
-template <int K, int KS, int MODE, int H, int NY, int NTX, bool BN>
+template <int K, int KS, int MODE, int H, int NY, int NTX, int RS, bool BN>
 int launch_bm(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0, uint16_t* o1,
               int N, int C, int W, hipStream_t st, float* stats, int* wpc_out, const BnIn* bn) {
     using B = BmGeo<K, NTX>;
+    using B1 = BmGeo<(KS > 0 ? KS : 5), NTX>;
     constexpr int SPLIT = H / NY, CPW = 4 / SPLIT;
     constexpr int NT_IN = (MODE == 1 && KS > 0) ? 2 : 1;
     if ((long)N * C * H * W >= (1L << 31) || (long)N * C * H * W < 8) return PPEA_ERR_UNSUPPORTED;   // (masked pieces read the tensor's first 16 bytes)
-    using B1 = BmGeo<(KS > 0 ? KS : 5), NTX>;
     int gi = 0, tile_bytes = 0, tile1_bytes = 0;
     for (int cand : {16, 12, 8, 4}) {                            // images per group: the largest whose tiles fit
         const int alloc = N < cand ? N : cand;
@@ -1082,32 +1189,44 @@ int launch_bm(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, cons
     }
     if (!gi) return PPEA_ERR_UNSUPPORTED;
     const int ngroups = (N + gi - 1) / gi;
-    if (wpc_out != nullptr) { *wpc_out = SPLIT * ngroups; return 0; }
+    // column tiles per workgroup: whole planes on the small maps; on wide maps enough workgroups to fill the chip
+    const int ntx_all = (W + 15) / 16;
+    int wgpc = 1;
+    if (ntx_all > NTX) {
+        const long base = (long)((C + CPW - 1) / CPW) * ngroups;
+        wgpc = (int)((256 + base - 1) / base);
+        if (wgpc < 1) wgpc = 1;
+        if (wgpc > ntx_all) wgpc = ntx_all;
+    }
+    const int cpw = (ntx_all + wgpc - 1) / wgpc;
+    wgpc = (ntx_all + cpw - 1) / cpw;
+    if (wpc_out != nullptr) { *wpc_out = SPLIT * ngroups * wgpc; return 0; }
     size_t lds = (size_t)CPW * (tile_bytes + tile1_bytes);
     if (lds < (size_t)4 * frag_scratch_bytes(K, KS)) lds = (size_t)4 * frag_scratch_bytes(K, KS);
-    auto kern = dwconv_bm_kernel<K, KS, MODE, H, NY, NTX, BN>;
+    auto kern = dwconv_bm_kernel<K, KS, MODE, H, NY, NTX, RS, BN>;
     const BnIn bnv = bn != nullptr ? *bn : BnIn{nullptr, 0, 0.f, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(((C + CPW - 1) / CPW) * ngroups)), dim3(256), lds, st, in0, in1, wb, ws, o0, o1,
-                       N, C, W, gi, ngroups, tile_bytes, tile1_bytes, stats, bnv);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(((C + CPW - 1) / CPW) * ngroups * wgpc)), dim3(256), lds, st, in0, in1, wb, ws,
+                       o0, o1, N, C, W, gi, ngroups, wgpc, cpw, tile_bytes, tile1_bytes, stats, bnv);
     return launch_status();
 }
 
-template <int K, int KS, int MODE, int H, int NY, int NTX>
+template <int K, int KS, int MODE, int H, int NY, int NTX, int RS>
 int launch_bm_n(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0, uint16_t* o1,
                 int N, int C, int W, hipStream_t st, float* stats, int* wpc_out, const BnIn* bn) {
     if constexpr (MODE == 0) {
-        if (bn != nullptr) return launch_bm<K, KS, MODE, H, NY, NTX, true>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, bn);
+        if (bn != nullptr) return launch_bm<K, KS, MODE, H, NY, NTX, RS, true>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, bn);
     }
     if (bn != nullptr) return PPEA_ERR_UNSUPPORTED;
-    return launch_bm<K, KS, MODE, H, NY, NTX, false>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, nullptr);
+    return launch_bm<K, KS, MODE, H, NY, NTX, RS, false>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, nullptr);
 }
 
-// The plane sizes this variant is built for: RepLKNet stages 1-3 of 192-row frames (24 x {64, 80}, 12 x {8..48}, 6 x {4..48}).
+// The plane sizes this variant is built for: RepLKNet stages 0-3 of 192-row frames (48 x W in segments, 24 x {64, 80},
+// 12 x {8..48}, 6 x {4..48}).
 template <int K, int KS, int MODE>
 int launch_bm_w(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const uint16_t* ws, uint16_t* o0, uint16_t* o1,
                 int N, int C, int H, int W, hipStream_t st, float* stats, int* wpc_out, const BnIn* bn) {
@@ -1115,11 +1234,23 @@ int launch_bm_w(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, co
     if (!on || (W & 3) != 0) return PPEA_ERR_UNSUPPORTED;
     const int ntx = (W + 15) / 16;
 #define PPEA_BM_NTX(H_, NTX_)                                                                                          \
-    if (H == H_ && ntx == NTX_) return launch_bm_n<K, KS, MODE, H_, 6, NTX_>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, bn);
+    if (H == H_ && ntx == NTX_) return launch_bm_n<K, KS, MODE, H_, 6, NTX_, 1>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, bn);
     if constexpr (KS == 5 && K == 29) { PPEA_BM_NTX(24, 4) PPEA_BM_NTX(24, 5) }
     if constexpr (KS == 5 && K == 27) { PPEA_BM_NTX(12, 1) PPEA_BM_NTX(12, 2) PPEA_BM_NTX(12, 3) }
     if constexpr (KS == 5 && K == 13) { PPEA_BM_NTX(6, 1) PPEA_BM_NTX(6, 2) PPEA_BM_NTX(6, 3) }
 #undef PPEA_BM_NTX
+    if constexpr (KS == 5 && K == 31 && MODE == 1) {
+        // 48-row planes (stage 0 of 192-row frames), data gradient only: 12 interleaved rows per wave, segments of 2 column
+        // tiles (two staged inputs), M = images -- worth it when the image groups fill most of the 16 MFMA rows (66 us
+        // against the row-band kernel's 74 at [12,128,48,160]).  The forward stays on the window-sharing row-band kernel:
+        // measured 65-73 us here against 58 (tools/bench_dwconv.py) -- all 256 workgroups stage their 129 KB segment at the
+        // same time with nothing to overlap it (one workgroup per CU, no registers left for a prefetch) and the epilogue's
+        // 32-byte runs per image cost as much as on the small maps.  PPEA_DW_BM48=0 disables the variant.
+        static const bool on48 = !(getenv("PPEA_DW_BM48") != nullptr && getenv("PPEA_DW_BM48")[0] == '0');
+        const int groups16 = (N + 15) / 16;
+        if (on48 && H == 48 && (W & 7) == 0 && 10 * N >= 7 * 16 * groups16)
+            return launch_bm_n<K, KS, MODE, 48, 12, 2, 4>(in0, in1, wb, ws, o0, o1, N, C, W, st, stats, wpc_out, bn);
+    }
     return PPEA_ERR_UNSUPPORTED;
 }
 
@@ -1192,6 +1323,9 @@ int launch_k(const uint16_t* in0, const uint16_t* in1, const uint16_t* wb, const
         const int err = launch_bm_w<K, KS, MODE>(in0, in1, wb, ws, o0, o1, N, C, H, W, st, stats, wpc_out, bn);
         if (err != PPEA_ERR_UNSUPPORTED) return err;
     }
+#ifdef PPEA_BM_ONLY                                              // (compile-time experiments with the batch-major variant alone)
+    return PPEA_ERR_UNSUPPORTED;
+#endif
     const long c5 = staged_cols<K>(W, 5), c3 = staged_cols<K>(W, 3), c2 = staged_cols<K>(W, 2);
     const int nseg = (c5 <= c3 && c5 <= c2) ? 5 : (c3 <= c2 ? 3 : 2);
     if constexpr (K == 31 && KS == 5) {

@@ -89,7 +89,9 @@ def test_dwconv_golden_reference(device, golden):
                                        # the batch-major variant (12 x W / 6 x W planes): full and ragged image groups, an
                                        # odd channel count (idle wave), 1 / 2 / 3 column tiles, W % 8 == 4
                                        (27, 12, 6, 12, 40), (27, 17, 2, 12, 40), (27, 20, 3, 12, 8), (27, 1, 1, 12, 24),
-                                       (13, 12, 8, 6, 20), (13, 18, 5, 6, 16), (13, 33, 2, 6, 44), (29, 12, 3, 24, 80), (29, 9, 2, 24, 64)])
+                                       (13, 12, 8, 6, 20), (13, 18, 5, 6, 16), (13, 33, 2, 6, 44), (29, 12, 3, 24, 80), (29, 9, 2, 24, 64),
+                                       # 48-row planes in column segments, interleaved rows (>= 12 of 16 MFMA rows filled)
+                                       (31, 12, 3, 48, 160), (31, 16, 2, 48, 56), (31, 30, 1, 48, 24)])
 def test_dwconv_bf16_mfma(device, K, N, C, H, W):
     """bf16 I/O on the matrix cores (banded-Toeplitz MFMA kernel): bf16 activations and bf16-rounded
     filters (what autocast feeds a conv), fp32 accumulation, one bf16 rounding of the output."""

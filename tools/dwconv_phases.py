@@ -33,7 +33,7 @@ for (K, C, H, W) in [(31, 128, 48, 160), (29, 256, 24, 80), (27, 512, 12, 40), (
     assert lib.ppea_debug_dwconv_prof(buf.ctypes.data_as(vp)) == 0
     act = buf[buf[:, 5] > 0].astype(np.float64)
     m = act.mean(0)
-    names = ["setup (filter image + fragments)", "staging per wave (all items)", "mac streams", "epilogues (cvt + stores)",
+    names = ["setup (filter image + fragments)", "staging per wave (all items)", "mac streams (bm: + epilogues)", "epilogues (bm: MFMA rows alone)",
              "items total", "kernel total", "  of setup: fragment construction"]
     print(f"k{K} [{N},{C},{H},{W}]: {len(act)} waves; shader-clock cycles per wave (s_memtime):")
     for i, nm in enumerate(names):
