@@ -208,6 +208,21 @@ int ppea_bn_bwd_channel_f32(const void* dy, const void* z1, const void* z2, cons
 int ppea_bn_bwd_channel_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats, const float* mask,
                              float inv_count, const void* acc, void* dz1, void* dz2, float* sums, int act, int N, int C,
                              int HW, void* stream);
+/* An output with TWO consumers (RepLKBlock / ConvFFN: the first 1x1 conv and the adapter both read the block's first
+ * BatchNorm, replknet_adapter.py:283-289, 315-326): dyb / dy2b = the second consumer's gradient.  The kernels start from
+ * round(dy + dyb) -- what a separate element-wise add would have stored -- so results are bit-identical to that form. */
+int ppea_bn_bwd_channel_dup_f32(const void* dy, const void* dyb, const void* z1, const void* z2, const float* const* stats,
+                                const float* mask, float inv_count, const void* acc, void* dz1, void* dz2, float* sums,
+                                int act, int N, int C, int HW, void* stream);
+int ppea_bn_bwd_channel_dup_bf16(const void* dy, const void* dyb, const void* z1, const void* z2, const float* const* stats,
+                                 const float* mask, float inv_count, const void* acc, void* dz1, void* dz2, float* sums,
+                                 int act, int N, int C, int HW, void* stream);
+int ppea_bn_bwd_channel_next_dup_f32(const void* dy2, const void* dy2b, const void* dskip, const void* z, const void* y,
+                                     const float* const* stats, const float* mask, float inv_count, void* dz, void* dy,
+                                     float* sums, int N, int C, int HW, void* stream);
+int ppea_bn_bwd_channel_next_dup_bf16(const void* dy2, const void* dy2b, const void* dskip, const void* z, const void* y,
+                                      const float* const* stats, const float* mask, float inv_count, void* dz, void* dy,
+                                      float* sums, int N, int C, int HW, void* stream);
 /* End of one block and the first BatchNorm of the next in one launch per direction (replknet_adapter.py:283-289,
  * 315-326 followed by the next block's prelkb_bn / preffn_bn, :281, :312): y = mask * BN_A(z) + r1 + r2_scale * r2,
  * y2 = BN_B(y) with BN_B's statistics taken of the stored y.  prm = {gammaA, betaA, gammaB, betaB}; out = {running_meanA,

@@ -565,7 +565,7 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel(const T* __restrict__ z1, 
 }
 
 template <typename T, bool TWO>
-__global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, const T* __restrict__ z1,
+__global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, const T* __restrict__ dyb, const T* __restrict__ z1,
                                                       const T* __restrict__ z2, Branch b1, Branch b2,
                                                       const float* __restrict__ mask, float inv_count,
                                                       const T* __restrict__ acc, T* __restrict__ dz1,
@@ -589,6 +589,12 @@ __global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, 
             ld8<T>(z1 + off, x1[u]);
             if constexpr (TWO) ld8<T>(z2 + off, x2[u]);
             ld8<T>(dy + off, gq[u]);
+            if (dyb != nullptr) {                            // the output's second consumer (see ppea_bn_bwd_channel_dup_*)
+                float gb[V];
+                ld8<T>(dyb + off, gb);
+#pragma unroll
+                for (int k = 0; k < V; ++k) gq[u][k] = round_as<T>(gq[u][k] + gb[k]);
+            }
         }
     }
 #pragma unroll
@@ -738,7 +744,7 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel_next(const T* __restrict__
 
 // sums [4][C] = d betaA | d gammaA | d betaB | d gammaB
 template <typename T>
-__global__ __launch_bounds__(TPB) void bn_bwd_channel_next(const T* __restrict__ dy2, const T* __restrict__ dskip,
+__global__ __launch_bounds__(TPB) void bn_bwd_channel_next(const T* __restrict__ dy2, const T* __restrict__ dy2b, const T* __restrict__ dskip,
                                                            const T* __restrict__ z, const T* __restrict__ y, Branch A,
                                                            Branch B, const float* __restrict__ mask, float inv_count,
                                                            T* __restrict__ dz, T* __restrict__ dy, float* __restrict__ sums,
@@ -757,6 +763,12 @@ __global__ __launch_bounds__(TPB) void bn_bwd_channel_next(const T* __restrict__
             const int n = j / hv, i = j - n * hv;
             const long off = ((long)n * C + c) * HW + i * V;
             ld8<T>(dy2 + off, g[u]);
+            if (dy2b != nullptr) {                           // y2's second consumer (see ppea_bn_bwd_channel_next_dup_*)
+                float gb[V];
+                ld8<T>(dy2b + off, gb);
+#pragma unroll
+                for (int k = 0; k < V; ++k) g[u][k] = round_as<T>(g[u][k] + gb[k]);
+            }
             ld8<T>(y + off, xd[u]);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
@@ -1031,17 +1043,17 @@ int fwd_channel_impl(const void* z1, const void* z2, const float* const* prm, fl
     return launch_status();
 }
 template <typename T>
-int bwd_channel_impl(const void* dy, const void* z1, const void* z2, const float* const* st, const float* mask,
+int bwd_channel_impl(const void* dy, const void* dyb, const void* z1, const void* z2, const float* const* st, const float* mask,
                      float inv_count, const void* acc, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW,
                      void* stream) {
     if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS || act < 0 || act > 2)
         return PPEA_ERR_UNSUPPORTED;
     Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
     if (z2 != nullptr)
-        hipLaunchKernelGGL((bn_bwd_channel<T, true>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy,
+        hipLaunchKernelGGL((bn_bwd_channel<T, true>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy, (const T*)dyb,
                            (const T*)z1, (const T*)z2, b1, b2, mask, inv_count, (const T*)acc, (T*)dz1, (T*)dz2, sums, act, N, C, HW);
     else
-        hipLaunchKernelGGL((bn_bwd_channel<T, false>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy,
+        hipLaunchKernelGGL((bn_bwd_channel<T, false>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy, (const T*)dyb,
                            (const T*)z1, (const T*)nullptr, b1, b2, mask, inv_count, (const T*)acc, (T*)dz1, (T*)nullptr, sums, act, N, C, HW);
     return launch_status();
 }
@@ -1057,12 +1069,12 @@ int fwd_channel_next_impl(const void* z, const float* const* prm, float* const* 
     return launch_status();
 }
 template <typename T>
-int bwd_channel_next_impl(const void* dy2, const void* dskip, const void* z, const void* y, const float* const* st,
+int bwd_channel_next_impl(const void* dy2, const void* dy2b, const void* dskip, const void* z, const void* y, const float* const* st,
                           const float* mask, float inv_count, void* dz, void* dy, float* sums, int N, int C, int HW,
                           void* stream) {
     if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS) return PPEA_ERR_UNSUPPORTED;
     Branch A{st[0], st[1], st[2], st[3]}, B{st[4], st[5], st[6], st[7]};
-    hipLaunchKernelGGL(bn_bwd_channel_next<T>, dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy2,
+    hipLaunchKernelGGL(bn_bwd_channel_next<T>, dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy2, (const T*)dy2b,
                        (const T*)dskip, (const T*)z, (const T*)y, A, B, mask, inv_count, (T*)dz, (T*)dy, sums, N, C, HW);
     return launch_status();
 }
@@ -1088,12 +1100,25 @@ int ppea_bn_fwd_channel_next_bf16(const void* z, const float* const* prm, float*
 int ppea_bn_bwd_channel_next_f32(const void* dy2, const void* dskip, const void* z, const void* y, const float* const* stats,
                                  const float* mask, float inv_count, void* dz, void* dy, float* sums, int N, int C, int HW,
                                  void* stream) {
-    return bwd_channel_next_impl<float>(dy2, dskip, z, y, stats, mask, inv_count, dz, dy, sums, N, C, HW, stream);
+    return bwd_channel_next_impl<float>(dy2, nullptr, dskip, z, y, stats, mask, inv_count, dz, dy, sums, N, C, HW, stream);
 }
 int ppea_bn_bwd_channel_next_bf16(const void* dy2, const void* dskip, const void* z, const void* y, const float* const* stats,
                                   const float* mask, float inv_count, void* dz, void* dy, float* sums, int N, int C, int HW,
                                   void* stream) {
-    return bwd_channel_next_impl<uint16_t>(dy2, dskip, z, y, stats, mask, inv_count, dz, dy, sums, N, C, HW, stream);
+    return bwd_channel_next_impl<uint16_t>(dy2, nullptr, dskip, z, y, stats, mask, inv_count, dz, dy, sums, N, C, HW, stream);
+}
+// As above for a y2 with TWO consumers (a block's first 1x1 conv and its adapter, rka.py:283-289, 315-326): dy2b = the second
+// consumer's gradient; the kernel starts from round(dy2 + dy2b), what the framework's separate element-wise add would have
+// stored, so every result is bit-identical to that form and the add launch is gone from the chain.
+int ppea_bn_bwd_channel_next_dup_f32(const void* dy2, const void* dy2b, const void* dskip, const void* z, const void* y,
+                                     const float* const* stats, const float* mask, float inv_count, void* dz, void* dy,
+                                     float* sums, int N, int C, int HW, void* stream) {
+    return bwd_channel_next_impl<float>(dy2, dy2b, dskip, z, y, stats, mask, inv_count, dz, dy, sums, N, C, HW, stream);
+}
+int ppea_bn_bwd_channel_next_dup_bf16(const void* dy2, const void* dy2b, const void* dskip, const void* z, const void* y,
+                                      const float* const* stats, const float* mask, float inv_count, void* dz, void* dy,
+                                      float* sums, int N, int C, int HW, void* stream) {
+    return bwd_channel_next_impl<uint16_t>(dy2, dy2b, dskip, z, y, stats, mask, inv_count, dz, dy, sums, N, C, HW, stream);
 }
 
 // One launch per BN for small channels (N * HW <= 16384, HW % 8 == 0, C >= 64; else PPEA_ERR_UNSUPPORTED):
@@ -1112,12 +1137,24 @@ int ppea_bn_fwd_channel_bf16(const void* z1, const void* z2, const float* const*
 int ppea_bn_bwd_channel_f32(const void* dy, const void* z1, const void* z2, const float* const* stats, const float* mask,
                             float inv_count, const void* acc, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW,
                             void* stream) {
-    return bwd_channel_impl<float>(dy, z1, z2, stats, mask, inv_count, acc, dz1, dz2, sums, act, N, C, HW, stream);
+    return bwd_channel_impl<float>(dy, nullptr, z1, z2, stats, mask, inv_count, acc, dz1, dz2, sums, act, N, C, HW, stream);
 }
 int ppea_bn_bwd_channel_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats, const float* mask,
                             float inv_count, const void* acc, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW,
                             void* stream) {
-    return bwd_channel_impl<uint16_t>(dy, z1, z2, stats, mask, inv_count, acc, dz1, dz2, sums, act, N, C, HW, stream);
+    return bwd_channel_impl<uint16_t>(dy, nullptr, z1, z2, stats, mask, inv_count, acc, dz1, dz2, sums, act, N, C, HW, stream);
+}
+// As above for an output with TWO consumers: dyb = the second consumer's gradient, the kernel starts from round(dy + dyb)
+// (bit-identical to a separate element-wise add followed by ppea_bn_bwd_channel_*).
+int ppea_bn_bwd_channel_dup_f32(const void* dy, const void* dyb, const void* z1, const void* z2, const float* const* stats,
+                                const float* mask, float inv_count, const void* acc, void* dz1, void* dz2, float* sums,
+                                int act, int N, int C, int HW, void* stream) {
+    return bwd_channel_impl<float>(dy, dyb, z1, z2, stats, mask, inv_count, acc, dz1, dz2, sums, act, N, C, HW, stream);
+}
+int ppea_bn_bwd_channel_dup_bf16(const void* dy, const void* dyb, const void* z1, const void* z2, const float* const* stats,
+                                 const float* mask, float inv_count, const void* acc, void* dz1, void* dz2, float* sums,
+                                 int act, int N, int C, int HW, void* stream) {
+    return bwd_channel_impl<uint16_t>(dy, dyb, z1, z2, stats, mask, inv_count, acc, dz1, dz2, sums, act, N, C, HW, stream);
 }
 
 // stats[8] = {mean1, invstd1, gamma1, beta1, mean2, invstd2, gamma2, beta2} (branch 2 NULL when z2 is NULL)

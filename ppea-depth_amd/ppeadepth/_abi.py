@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libppea_depth.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -115,6 +115,10 @@ SIGNATURES = {
     "ppea_bn_fwd_channel_next_bf16": [_vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
     "ppea_bn_bwd_channel_next_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ppea_bn_bwd_channel_next_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ppea_bn_bwd_channel_dup_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_bn_bwd_channel_dup_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_bn_bwd_channel_next_dup_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ppea_bn_bwd_channel_next_dup_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ppea_conv_image_packed_bytes": [_i, _i],
     "ppea_conv_image_pack_weights": [_vp, _i, _vp, _i, _i, _i, _vp],
     "ppea_conv_image_bf16": [_vp, _vp, _vp] + [_i] * 10 + [_vp],

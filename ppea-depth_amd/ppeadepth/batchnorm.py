@@ -237,8 +237,12 @@ def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None,
             and bn1.running_mean.dtype == torch.float32):
         z1_skip = z1
         if skip and torch.is_grad_enabled() and z1.requires_grad:
-            y, st, z1_skip = ops.bn_act_channel(z1, bn1, z2, bn2, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act,
-                                                skip=True)
+            if BN_DUP and r1 is None and r2 is None:
+                y, st, z1_skip, y_b = ops.bn_act_channel(z1, bn1, z2, bn2, mask=mask, act=act, skip=True, dup=True)
+                y._second_use = y_b                      # see second_use()
+            else:
+                y, st, z1_skip = ops.bn_act_channel(z1, bn1, z2, bn2, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act,
+                                                    skip=True)
         else:
             y, st = ops.bn_act_channel(z1, bn1, z2, bn2, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act)
         cnt = float(z1.numel() // z1.shape[1])
@@ -276,6 +280,15 @@ def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None,
 
 
 BN_CHAIN = __import__("os").environ.get("PPEA_BN_CHAIN", "1") == "1"
+# A block's first BatchNorm output feeds its first 1x1 conv AND its adapter: hand the adapter an alias of it whose gradient
+# arrives separately at the BatchNorm's backward launch, which adds the two (bit-identical to autograd's own add kernel,
+# one launch fewer on the dependent chain per block and network)
+BN_DUP = __import__("os").environ.get("PPEA_BN_DUP", "1") == "1"
+
+
+def second_use(y):
+    """The tensor to hand to the SECOND consumer of a fused BatchNorm output (itself where no alias was made)."""
+    return getattr(y, "_second_use", y)
 
 
 def fused_bn_act_next(z, bnA, bnB, mask=None, r1=None, r2=None, r2_scale=1.0):
@@ -300,7 +313,11 @@ def fused_bn_act_next(z, bnA, bnB, mask=None, r1=None, r2=None, r2_scale=1.0):
             and bnA.running_mean.dtype == torch.float32 and bnB.running_mean.dtype == torch.float32
             and bnA.num_features == bnB.num_features):
         return None
-    y, y2, st = ops.bn_act_channel_next(z, bnA, bnB, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale)
+    if BN_DUP and torch.is_grad_enabled() and z.requires_grad:
+        y, y2, st, y2_b = ops.bn_act_channel_next(z, bnA, bnB, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, dup=True)
+        y2._second_use = y2_b
+    else:
+        y, y2, st = ops.bn_act_channel_next(z, bnA, bnB, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale)
     cnt = float(z.numel() // z.shape[1])
     for k, bn in enumerate((bnA, bnB)):
         if _ACTIVE_DEFERRED is None:

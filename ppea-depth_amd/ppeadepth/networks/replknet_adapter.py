@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops, rng
-from ..batchnorm import BatchNorm2d, fused_bn_act, fused_bn_act_next
+from ..batchnorm import BatchNorm2d, fused_bn_act, fused_bn_act_next, second_use
 
 FUSE_BN = True      # training-mode BN + activation + residual glue on the fused HIP kernels
 ADAPTER_CHANNELS_LAST = True
@@ -404,10 +404,11 @@ class ConvFFN(nn.Module):
                 out, x = fused_bn_act(x, self.preffn_bn, skip=True)    # x: the same tensor, routed for the residual use
             adpt, join = None, None
             if self.test_id >= 0:
+                a_in = second_use(out)       # an alias of `out`: its gradient joins pw1's inside the BatchNorm's backward launch
                 if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
-                    adpt, join = _forked_adapter(self.mlp_adapter, out)
+                    adpt, join = _forked_adapter(self.mlp_adapter, a_in)
                 else:
-                    adpt = self.mlp_adapter(out)
+                    adpt = self.mlp_adapter(a_in)
             z1, s1 = _conv_sums(self.pw1.conv, out)
             h = fused_bn_act(z1, self.pw1.bn, act=ops.ACT_GELU, sums=s1)
             z, s2 = _conv_sums(self.pw2.conv, h)
@@ -484,10 +485,11 @@ class RepLKBlock(nn.Module):
                 out, x = fused_bn_act(x, self.prelkb_bn, skip=True)    # x: the same tensor, routed for the residual use
             adpt, join = None, None
             if self.test_id >= 0:
+                a_in = second_use(out)       # (see ConvFFN.forward)
                 if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
-                    adpt, join = _forked_adapter(self.adapter, out)
+                    adpt, join = _forked_adapter(self.adapter, a_in)
                 else:
-                    adpt = self.adapter(out)
+                    adpt = self.adapter(a_in)
             t = self._pw1_large_kernel_fused(out)
             if t is None:
                 t = self.large_kernel.forward_act(self.pw1(out), ops.ACT_RELU)

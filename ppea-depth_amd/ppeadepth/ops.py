@@ -621,7 +621,8 @@ class _BnActChannel(torch.autograd.Function):
     the saved (mean, invstd) in ONE launch; backward (sums + dz) in one launch."""
 
     @staticmethod
-    def forward(ctx, z1, g1, b1, rm1, rv1, z2, g2, b2, rm2, rv2, mask, r1, r2, r2_scale, act, eps, momentum, skip=False):
+    def forward(ctx, z1, g1, b1, rm1, rv1, z2, g2, b2, rm2, rv2, mask, r1, r2, r2_scale, act, eps, momentum, skip=False,
+                dup=False):
         z1_in = z1
         z1 = z1.contiguous()
         N, C = z1.shape[0], z1.shape[1]
@@ -645,21 +646,31 @@ class _BnActChannel(torch.autograd.Function):
         ctx.pdt = (g1.dtype, b1.dtype, None if g2 is None else g2.dtype)
         ctx.mark_non_differentiable(st)
         ctx.set_materialize_grads(False)         # no zero-filled "gradient" of the statistics output per backward call
-        ctx.skip = bool(skip)
+        ctx.skip, ctx.dup = bool(skip), bool(dup)
+        outs = (y, st)
         if skip:
             # third output: z1 itself, for the block's residual use -- its gradient comes back HERE and is added in the
             # backward launch (autograd would otherwise add the two gradients of z1 with one more element-wise kernel)
-            return y, st, z1_in
-        return y, st
+            outs += (z1_in,)
+        if dup:
+            # last output: y once more (same storage) for its SECOND consumer (a block's adapter next to its first 1x1
+            # conv): the two gradients arrive separately and are added in the backward launch
+            outs += (y.detach(),)
+        return outs
 
     @staticmethod
-    def backward(ctx, dy, _dst, dskip=None):
+    def backward(ctx, dy, _dst, *rest):
+        rest = list(rest)
+        dskip = rest.pop(0) if ctx.skip else None
+        dyb = rest.pop(0) if ctx.dup else None
         z1, z2, st, g1f, b1f, g2f, b2f, maskf = ctx.saved_tensors
         N, C = z1.shape[0], z1.shape[1]
         HW = z1.numel() // (N * C)
         if dy is None:
-            dy = torch.zeros_like(z1)
+            dy, dyb = (dyb, None) if dyb is not None else (torch.zeros_like(z1), None)
         dy = dy.contiguous().to(z1.dtype)
+        if dyb is not None:
+            dyb = dyb.contiguous().to(z1.dtype)
         sums = torch.empty(3, C, device=z1.device, dtype=_F32)
         dz1 = torch.empty_like(z1)
         dz2 = None if z2 is None else torch.empty_like(z2)
@@ -667,24 +678,33 @@ class _BnActChannel(torch.autograd.Function):
                               st[3] if z2 is not None else None, g2f, b2f))
         if dskip is not None:
             dskip = dskip.contiguous().to(z1.dtype)
-        call(f"ppea_bn_bwd_channel_{_suffix(z1)}", ptr(dy), ptr(z1), ptr(z2), stats, ptr(maskf), 1.0 / float(N * HW),
-             ptr(dskip), ptr(dz1), ptr(dz2), ptr(sums), ctx.act, N, C, HW, stream_ptr())
+        if dyb is not None:
+            if ctx.has[0] or ctx.has[1]:
+                dy = dy + dyb                                # (r1 / r2 receive dy itself: not a block's first BatchNorm)
+                dyb = None
+        if dyb is not None:
+            call(f"ppea_bn_bwd_channel_dup_{_suffix(z1)}", ptr(dy), ptr(dyb), ptr(z1), ptr(z2), stats, ptr(maskf),
+                 1.0 / float(N * HW), ptr(dskip), ptr(dz1), ptr(dz2), ptr(sums), ctx.act, N, C, HW, stream_ptr())
+        else:
+            call(f"ppea_bn_bwd_channel_{_suffix(z1)}", ptr(dy), ptr(z1), ptr(z2), stats, ptr(maskf), 1.0 / float(N * HW),
+                 ptr(dskip), ptr(dz1), ptr(dz2), ptr(sums), ctx.act, N, C, HW, stream_ptr())
         dg1 = sums[1].to(ctx.pdt[0]) if ctx.needs_input_grad[1] else None
         db1 = sums[0].to(ctx.pdt[1]) if ctx.needs_input_grad[2] else None
         dg2 = sums[2].to(ctx.pdt[2]) if (z2 is not None and ctx.needs_input_grad[6]) else None
         db2 = sums[0].to(ctx.pdt[2]) if (z2 is not None and ctx.needs_input_grad[7]) else None
         dr1 = dy if ctx.has[0] else None
         dr2 = (dy if ctx.r2_scale == 1.0 else dy * ctx.r2_scale) if ctx.has[1] else None
-        return (dz1, dg1, db1, None, None, dz2, dg2, db2, None, None, None, dr1, dr2, None, None, None, None, None)
+        return (dz1, dg1, db1, None, None, dz2, dg2, db2, None, None, None, dr1, dr2, None, None, None, None, None, None)
 
 
-def bn_act_channel(z1, bn1, z2=None, bn2=None, mask=None, r1=None, r2=None, r2_scale=1.0, act=ACT_NONE, skip=False):
-    """-> (y, stats [4,C] = mean1 | invstd1 | mean2 | invstd2 [, z1 for the residual use when `skip`]).  Updates the
-    running statistics of bn1 / bn2."""
+def bn_act_channel(z1, bn1, z2=None, bn2=None, mask=None, r1=None, r2=None, r2_scale=1.0, act=ACT_NONE, skip=False,
+                   dup=False):
+    """-> (y, stats [4,C] = mean1 | invstd1 | mean2 | invstd2 [, z1 for the residual use when `skip`] [, y again for its
+    second consumer when `dup`]).  Updates the running statistics of bn1 / bn2."""
     return _BnActChannel.apply(z1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, z2,
                                None if bn2 is None else bn2.weight, None if bn2 is None else bn2.bias,
                                None if bn2 is None else bn2.running_mean, None if bn2 is None else bn2.running_var,
-                               mask, r1, r2, r2_scale, act, bn1.eps, bn1.momentum, skip)
+                               mask, r1, r2, r2_scale, act, bn1.eps, bn1.momentum, skip, dup)
 
 
 class _BnActChannelNext(torch.autograd.Function):
@@ -693,7 +713,7 @@ class _BnActChannelNext(torch.autograd.Function):
     _BnActChannel(y, B, skip=True)."""
 
     @staticmethod
-    def forward(ctx, z, gA, bA, rmA, rvA, gB, bB, rmB, rvB, mask, r1, r2, r2_scale, eps, momentum):
+    def forward(ctx, z, gA, bA, rmA, rvA, gB, bB, rmB, rvB, mask, r1, r2, r2_scale, eps, momentum, dup=False):
         z = z.contiguous()
         N, C = z.shape[0], z.shape[1]
         HW = z.numel() // (N * C)
@@ -714,22 +734,28 @@ class _BnActChannelNext(torch.autograd.Function):
         ctx.pdt = (gA.dtype, bA.dtype, gB.dtype, bB.dtype)
         ctx.mark_non_differentiable(st)
         ctx.set_materialize_grads(False)
+        if dup:                                              # y2 once more for its second consumer (see _BnActChannel)
+            return y, y2, st, y2.detach()
         return y, y2, st
 
     @staticmethod
-    def backward(ctx, dy, dy2, _dst):
+    def backward(ctx, dy, dy2, _dst, dy2b=None):
         z, y, st, gAf, bAf, gBf, bBf, maskf = ctx.saved_tensors
         N, C = z.shape[0], z.shape[1]
         HW = z.numel() // (N * C)
         if dy2 is None:
-            dy2 = torch.zeros_like(z)
+            dy2, dy2b = (dy2b, None) if dy2b is not None else (torch.zeros_like(z), None)
         dy2 = dy2.contiguous().to(z.dtype)
         dskip = None if dy is None else dy.contiguous().to(z.dtype)
         sums = torch.empty(4, C, device=z.device, dtype=_F32)
         dz, dyt = torch.empty_like(z), torch.empty_like(z)
         stats = _stats_array((st[0], st[1], gAf, bAf, st[2], st[3], gBf, bBf))
-        call(f"ppea_bn_bwd_channel_next_{_suffix(z)}", ptr(dy2), ptr(dskip), ptr(z), ptr(y), stats, ptr(maskf),
-             1.0 / float(N * HW), ptr(dz), ptr(dyt), ptr(sums), N, C, HW, stream_ptr())
+        if dy2b is not None:
+            call(f"ppea_bn_bwd_channel_next_dup_{_suffix(z)}", ptr(dy2), ptr(dy2b.contiguous().to(z.dtype)), ptr(dskip), ptr(z),
+                 ptr(y), stats, ptr(maskf), 1.0 / float(N * HW), ptr(dz), ptr(dyt), ptr(sums), N, C, HW, stream_ptr())
+        else:
+            call(f"ppea_bn_bwd_channel_next_{_suffix(z)}", ptr(dy2), ptr(dskip), ptr(z), ptr(y), stats, ptr(maskf),
+                 1.0 / float(N * HW), ptr(dz), ptr(dyt), ptr(sums), N, C, HW, stream_ptr())
         n = ctx.needs_input_grad
         dgA = sums[1].to(ctx.pdt[0]) if n[1] else None
         dbA = sums[0].to(ctx.pdt[1]) if n[2] else None
@@ -737,13 +763,14 @@ class _BnActChannelNext(torch.autograd.Function):
         dbB = sums[2].to(ctx.pdt[3]) if n[6] else None
         dr1 = dyt if ctx.has[0] else None
         dr2 = (dyt if ctx.r2_scale == 1.0 else dyt * ctx.r2_scale) if ctx.has[1] else None
-        return (dz, dgA, dbA, None, None, dgB, dbB, None, None, None, dr1, dr2, None, None, None)
+        return (dz, dgA, dbA, None, None, dgB, dbB, None, None, None, dr1, dr2, None, None, None, None)
 
 
-def bn_act_channel_next(z, bnA, bnB, mask=None, r1=None, r2=None, r2_scale=1.0):
-    """-> (y, y2, stats [4,C] = meanA | invstdA | meanB | invstdB).  Updates the running statistics of both BNs."""
+def bn_act_channel_next(z, bnA, bnB, mask=None, r1=None, r2=None, r2_scale=1.0, dup=False):
+    """-> (y, y2, stats [4,C] = meanA | invstdA | meanB | invstdB [, y2 again for its second consumer when `dup`]).  Updates
+    the running statistics of both BNs."""
     return _BnActChannelNext.apply(z, bnA.weight, bnA.bias, bnA.running_mean, bnA.running_var, bnB.weight, bnB.bias,
-                                   bnB.running_mean, bnB.running_var, mask, r1, r2, r2_scale, bnA.eps, bnA.momentum)
+                                   bnB.running_mean, bnB.running_var, mask, r1, r2, r2_scale, bnA.eps, bnA.momentum, dup)
 
 
 # ---------------------------------------------------------------------------------------------

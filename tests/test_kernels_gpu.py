@@ -1171,6 +1171,54 @@ def test_block_chain_last_bn_plus_next_pre_bn_is_bit_identical(device, dtype="bf
         assert torch.equal(a[3][n], b[3][n]), n
 
 
+@pytest.mark.parametrize("chain", [True, False])
+def test_bn_second_consumer_gradient_added_in_the_backward_launch_is_bit_identical(device, chain):
+    """A block's first BatchNorm output feeds its first 1x1 conv and its adapter.  With BN_DUP the adapter reads an alias whose
+    gradient reaches the BatchNorm's backward launch separately and is added there (round(dy + dyb), then the usual
+    arithmetic) instead of by autograd's own element-wise kernel: a whole stage must agree BITWISE with and without it --
+    output, input gradient, every parameter gradient, every running statistic -- and launch fewer add kernels."""
+    from oracle import synth
+    from torch.profiler import ProfilerActivity, profile
+    from ppeadepth import batchnorm, rng
+    from ppeadepth.networks import replknet_adapter as rka
+    C, K, H, W, B = 128, 13, 12, 20, 3
+
+    def run(dup):
+        saved = (batchnorm.BN_DUP, batchnorm.BN_CHAIN)
+        batchnorm.BN_DUP, batchnorm.BN_CHAIN = dup, chain
+        try:
+            st = rka.RepLKNetStage(C, 2, K, [0.1, 0.2], 5, adpt_test=4, ratio=0.25)
+            synth.fill_state_dict(st)
+            st = st.to(device).train()
+            for n, p in st.named_parameters():
+                p.requires_grad = "adapter" in n or ".bn" in n or "_bn" in n
+            g = _g(5)
+            x = torch.randn(B, C, H, W, generator=g).to(device).requires_grad_(True)
+            go = torch.randn(B, C, H, W, generator=g).to(device)
+            rng.set_mode("reference")
+            torch.manual_seed(11)
+            with profile(activities=[ProfilerActivity.CPU]) as prof:
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = st(x.bfloat16())
+                y.backward(go.bfloat16())
+            torch.cuda.synchronize()
+            adds = sum(1 for e in prof.events() if e.name in ("aten::add_", "aten::add"))
+            grads = {n: p.grad for n, p in st.named_parameters() if p.grad is not None}
+            return y.detach(), x.grad, grads, {n: b.clone() for n, b in st.named_buffers()}, adds
+        finally:
+            batchnorm.BN_DUP, batchnorm.BN_CHAIN = saved
+            rng.set_mode("device")
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert a[2].keys() == b[2].keys() and len(a[2]) > 20
+    for n in a[2]:
+        assert torch.equal(a[2][n], b[2][n]), n
+    for n in a[3]:
+        assert torch.equal(a[3][n], b[3][n]), n
+    assert b[4] <= a[4] - 3, (a[4], b[4])              # 4 blocks: at least 3 element-wise adds gone
+
+
 # ---- round 3: the remaining library holes (VERDICT r2 #6) ---------------------------------------------------------------
 @pytest.mark.parametrize("kind,C,hidden", [("mlp", 192, 48), ("conv", 192, 48), ("mlp", 128, 148), ("conv", 64, 20)])
 def test_adapters_with_ragged_hidden_width_run_on_the_mfma_kernels(device, kind, C, hidden):

@@ -20,22 +20,27 @@ random.seed(1000)
 for _ in range(2):
     engine.step(dict(inputs))
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     engine.step(dict(inputs))
     torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0])
+shapes = collections.defaultdict(collections.Counter)
 for ev in prof.events():
-    if not ev.name.startswith("aten::") or ev.device_time_total <= 0 or ev.cpu_children:
+    t = getattr(ev, "self_device_time_total", 0)
+    if not ev.name.startswith("aten::") or t <= 0:
         continue
-    frame = "?"
+    frame = "(autograd engine / no python frame)"
     for fr in (ev.stack or []):
-        if "ppeadepth" in fr or "bench" in fr:
-            frame = fr.split("ppeadepth/")[-1][:70]
+        if "ppeadepth/" in fr:
+            frame = fr.split("ppeadepth/")[-1][:80]
             break
     key = (ev.name, frame)
     agg[key][0] += 1
-    agg[key][1] += ev.device_time_total
+    agg[key][1] += t
+    shapes[key][str(ev.input_shapes)[:90]] += 1
 tot = sum(v[1] for v in agg.values())
-print(f"{tot / 1e3:.2f} ms of device time in leaf aten ops in one eager step")
-for (name, frame), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
-    print(f"{t / 1e3:8.3f} ms {n:5d}  {name:34s} {frame}")
+print(f"{tot / 1e3:.2f} ms of device time in aten ops (self) in one eager step")
+for key, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:50]:
+    print(f"{t / 1e3:8.3f} ms {n:5d}  {key[0]:28s} {key[1]}")
+    for sh, k in shapes[key].most_common(3):
+        print(f"                    {k:4d} x {sh}")
