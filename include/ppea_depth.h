@@ -223,6 +223,14 @@ int ppea_bn_bwd_channel_next_dup_f32(const void* dy2, const void* dy2b, const vo
 int ppea_bn_bwd_channel_next_dup_bf16(const void* dy2, const void* dy2b, const void* dskip, const void* z, const void* y,
                                       const float* const* stats, const float* mask, float inv_count, void* dz, void* dy,
                                       float* sums, int N, int C, int HW, void* stream);
+/* Several ranks (reduce -> all-reduce -> apply): the reduce launch merges the two gradients and stores dym = round(dy + dyb)
+ * for the apply launch.  Limits of ppea_bn_bwd_reduce_final_*. */
+int ppea_bn_bwd_reduce_final_dup_f32(const void* dy, const void* dyb, void* dym, const void* z1, const void* z2,
+                                     const float* const* stats, const float* mask, float* sums, int act, int N, int C,
+                                     int HW, void* stream);
+int ppea_bn_bwd_reduce_final_dup_bf16(const void* dy, const void* dyb, void* dym, const void* z1, const void* z2,
+                                      const float* const* stats, const float* mask, float* sums, int act, int N, int C,
+                                      int HW, void* stream);
 /* End of one block and the first BatchNorm of the next in one launch per direction (replknet_adapter.py:283-289,
  * 315-326 followed by the next block's prelkb_bn / preffn_bn, :281, :312): y = mask * BN_A(z) + r1 + r2_scale * r2,
  * y2 = BN_B(y) with BN_B's statistics taken of the stored y.  prm = {gammaA, betaA, gammaB, betaB}; out = {running_meanA,
@@ -508,6 +516,9 @@ int ppea_nhwc_bias_elu_bwd_bf16(const void* dy, const void* y, void* dz, float* 
  * ---------------------------------------------------------------------------------------- */
 int ppea_adam_flat_f32(float* p, const float* g, float* m, float* v, void* w16, long n, long n_lo,
                        const float* state, float beta1, float beta2, float eps, void* stream);
+/* The same step on g * grad_scale (data-parallel mean of rank-summed gradients without a scaling pass of its own). */
+int ppea_adam_flat_scaled_f32(float* p, const float* g, float* m, float* v, void* w16, long n, long n_lo,
+                              const float* state, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

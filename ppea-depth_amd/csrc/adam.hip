@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         uint16_t* __restrict__ w16, long n, long n_lo,
                                                         const float* __restrict__ state, float b1, float b2,
-                                                        float eps) {
+                                                        float eps, float gscale) {
     const float t = state[0], lr = state[1];
     const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
     const float step_size = lr / bc1, sq_bc2 = sqrtf(bc2);
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
         const float4 gg = reinterpret_cast<const float4*>(g)[i];
         float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
         float4 pp = reinterpret_cast<float4*>(p)[i];
-        const float ga[4] = {gg.x, gg.y, gg.z, gg.w};
+        const float ga[4] = {gg.x * gscale, gg.y * gscale, gg.z * gscale, gg.w * gscale};
         float ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w}, pa[4] = {pp.x, pp.y, pp.z, pp.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, c
     const long tail0 = n4 << 2;
     const long j = tail0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) {
-        const float gj = g[j];
+        const float gj = g[j] * gscale;
         const float mj = m[j] + (1.f - b1) * (gj - m[j]);
         const float vj = b2 * v[j] + (1.f - b2) * gj * gj;
         const float pj = p[j] - step_size * mj / (sqrtf(vj) / sq_bc2 + eps);
@@ -70,7 +70,21 @@ int ppea_adam_flat_f32(float* p, const float* g, float* m, float* v, void* w16, 
     if (blocks < 1) blocks = 1;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                       (uint16_t*)w16, n, n_lo, state, beta1, beta2, eps);
+                       (uint16_t*)w16, n, n_lo, state, beta1, beta2, eps, 1.f);
+    return launch_status();
+}
+
+// The same step on g * grad_scale (one fp32 multiply per element, i.e. the values a separate scaling pass would have
+// stored): data-parallel training sums the gradients over the ranks and divides by their number here instead of in a pass of
+// its own over the gradient buffer (trainer.py:215-222: DDP's mean).
+int ppea_adam_flat_scaled_f32(float* p, const float* g, float* m, float* v, void* w16, long n, long n_lo, const float* state,
+                              float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    if (n <= 0 || n_lo < 0 || n_lo > n) return PPEA_ERR_UNSUPPORTED;
+    long blocks = ((n >> 2) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       (uint16_t*)w16, n, n_lo, state, beta1, beta2, eps, grad_scale);
     return launch_status();
 }
 

@@ -435,7 +435,8 @@ __global__ __launch_bounds__(TPB) void bn_stats_channel(const T* __restrict__ z,
 }
 
 template <typename T>
-__global__ __launch_bounds__(TPB) void bn_bwd_reduce_channel(const T* __restrict__ dy, const T* __restrict__ z1,
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_channel(const T* __restrict__ dy, const T* __restrict__ dyb,
+                                                             T* __restrict__ dym, const T* __restrict__ z1,
                                                              const T* __restrict__ z2, Branch b1, Branch b2,
                                                              const float* __restrict__ mask, float* __restrict__ sums,
                                                              int act, int N, int C, int HW) {
@@ -458,6 +459,13 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_channel(const T* __restrict
         ld8<T>(z1 + base, x1);
         if (z2 != nullptr) ld8<T>(z2 + base, x2);
         ld8<T>(dy + base, d);
+        if (dyb != nullptr) {                                // second consumer's gradient: merge, and leave the sum for the apply launch
+            float gb[V];
+            ld8<T>(dyb + base, gb);
+#pragma unroll
+            for (int k = 0; k < V; ++k) d[k] = round_as<T>(d[k] + gb[k]);
+            st8<T>(dym + base, d);
+        }
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             float u2 = a1 * x1[k] + o1;
@@ -1018,12 +1026,13 @@ int stats_packed_impl(const void* z, int N, int C, int HW, float* packed, void* 
     return launch_status();
 }
 template <typename T>
-int bwd_reduce_final_impl(const void* dy, const void* z1, const void* z2, const float* const* st, const float* mask,
-                          float* sums, int act, int N, int C, int HW, void* stream) {
+int bwd_reduce_final_impl(const void* dy, const void* dyb, void* dym, const void* z1, const void* z2, const float* const* st,
+                          const float* mask, float* sums, int act, int N, int C, int HW, void* stream) {
+    if ((dyb == nullptr) != (dym == nullptr)) return PPEA_ERR_ARG;
     if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS) return PPEA_ERR_UNSUPPORTED;
     Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
     hipLaunchKernelGGL(bn_bwd_reduce_channel<T>, dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream,
-                       (const T*)dy, (const T*)z1, (const T*)z2, b1, b2, mask, sums, act, N, C, HW);
+                       (const T*)dy, (const T*)dyb, (T*)dym, (const T*)z1, (const T*)z2, b1, b2, mask, sums, act, N, C, HW);
     return launch_status();
 }
 
@@ -1188,11 +1197,23 @@ int ppea_bn_stats_final_bf16(const void* z, int N, int C, int HW, float eps, flo
 }
 int ppea_bn_bwd_reduce_final_f32(const void* dy, const void* z1, const void* z2, const float* const* stats,
                                  const float* mask, float* sums, int act, int N, int C, int HW, void* stream) {
-    return bwd_reduce_final_impl<float>(dy, z1, z2, stats, mask, sums, act, N, C, HW, stream);
+    return bwd_reduce_final_impl<float>(dy, nullptr, nullptr, z1, z2, stats, mask, sums, act, N, C, HW, stream);
 }
 int ppea_bn_bwd_reduce_final_bf16(const void* dy, const void* z1, const void* z2, const float* const* stats,
                                   const float* mask, float* sums, int act, int N, int C, int HW, void* stream) {
-    return bwd_reduce_final_impl<uint16_t>(dy, z1, z2, stats, mask, sums, act, N, C, HW, stream);
+    return bwd_reduce_final_impl<uint16_t>(dy, nullptr, nullptr, z1, z2, stats, mask, sums, act, N, C, HW, stream);
+}
+// Several ranks, an output with two consumers (see ppea_bn_bwd_channel_dup_*): the reduce launch starts from dym = round(dy +
+// dyb), which it also stores for the apply launch that follows the all-reduce.
+int ppea_bn_bwd_reduce_final_dup_f32(const void* dy, const void* dyb, void* dym, const void* z1, const void* z2,
+                                     const float* const* stats, const float* mask, float* sums, int act, int N, int C,
+                                     int HW, void* stream) {
+    return bwd_reduce_final_impl<float>(dy, dyb, dym, z1, z2, stats, mask, sums, act, N, C, HW, stream);
+}
+int ppea_bn_bwd_reduce_final_dup_bf16(const void* dy, const void* dyb, void* dym, const void* z1, const void* z2,
+                                      const float* const* stats, const float* mask, float* sums, int act, int N, int C,
+                                      int HW, void* stream) {
+    return bwd_reduce_final_impl<uint16_t>(dy, dyb, dym, z1, z2, stats, mask, sums, act, N, C, HW, stream);
 }
 int ppea_bn_stats_packed_f32(const void* z, int N, int C, int HW, float* packed, void* stream) {
     return stats_packed_impl<float>(z, N, C, HW, packed, stream);

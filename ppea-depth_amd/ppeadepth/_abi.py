@@ -64,6 +64,7 @@ SIGNATURES = {
     "ppea_nhwc_bias_elu_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "ppea_nhwc_bias_elu_bwd_bf16": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "ppea_adam_flat_f32": [_vp, _vp, _vp, _vp, _vp, ctypes.c_long, ctypes.c_long, _vp, _f, _f, _f, _vp],
+    "ppea_adam_flat_scaled_f32": [_vp, _vp, _vp, _vp, _vp, ctypes.c_long, ctypes.c_long, _vp, _f, _f, _f, _f, _vp],
     "ppea_tapsum_fwd_bf16": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_tapsum_bwd_bf16": [_vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_bn_stats_f32": [_vp, _vp, _i, _i, _i, _vp],
@@ -119,6 +120,8 @@ SIGNATURES = {
     "ppea_bn_bwd_channel_dup_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_bn_bwd_channel_next_dup_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ppea_bn_bwd_channel_next_dup_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ppea_bn_bwd_reduce_final_dup_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_bn_bwd_reduce_final_dup_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_conv_image_packed_bytes": [_i, _i],
     "ppea_conv_image_pack_weights": [_vp, _i, _vp, _i, _i, _i, _vp],
     "ppea_conv_image_bf16": [_vp, _vp, _vp] + [_i] * 10 + [_vp],

@@ -227,9 +227,12 @@ def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None,
     if _sync_path_ok(z1, [bn for _, bn in bns]):
         # several ranks: [statistics launch] -> all-gather -> combine + apply launch (same fused neighbours as below)
         want_skip = bool(skip and torch.is_grad_enabled() and z1.requires_grad)
+        want_dup = bool(want_skip and BN_DUP and r1 is None and r2 is None and ops.bn_channel_ok(z1))
         outs = ops.sync_bn_act(z1, bn1, z2, bn2, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act,
-                               group=getattr(bn1, "group", None), sums=sums, skip=want_skip)
+                               group=getattr(bn1, "group", None), sums=sums, skip=want_skip, dup=want_dup)
         _book_sync(bns, outs[1], z1)
+        if want_dup:
+            outs[0]._second_use = outs[-1]
         return (outs[0], outs[2] if want_skip else z1) if skip else outs[0]
     # small channels on one rank: statistics, running-statistics update and apply in ONE launch (backward likewise)
     if (ops.bn_channel_ok(z1) and all(bn.training for _, bn in bns) and not any(bn.sync and _collectives_on() for _, bn in bns)
@@ -304,8 +307,10 @@ def fused_bn_act_next(z, bnA, bnB, mask=None, r1=None, r2=None, r2_scale=1.0):
         y, stA, tab = ops.sync_bn_act(z, bnA, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, group=group, emit=True)
         _book_sync([(z, bnA)], stA, z)
         want_skip = bool(torch.is_grad_enabled() and y.requires_grad)
-        outs = ops.sync_bn_act(y, bnB, group=group, table=tab, skip=want_skip)
+        outs = ops.sync_bn_act(y, bnB, group=group, table=tab, skip=want_skip, dup=bool(want_skip and BN_DUP))
         _book_sync([(y, bnB)], outs[1], y)
+        if want_skip and BN_DUP:
+            outs[0]._second_use = outs[-1]
         return (outs[2] if want_skip else y), outs[0]
     if not (BN_CHAIN and ops.bn_channel_ok(z) and bnA.training and bnB.training
             and not ((bnA.sync or bnB.sync) and _collectives_on())

@@ -101,6 +101,7 @@ class FlatGrads:
 
     def __init__(self, targets, n_chunks=4, align=1):
         self.targets = list(targets)
+        self.scale_in_optimizer = False    # True: the exchange leaves the SUM over ranks, the optimizer kernel divides by world
         device = self.targets[0].device
         # every tensor starts at a multiple of `align` elements (flat optimizer: parameter views keep the
         # 256-byte alignment the GEMM / conv kernels expect of a weight pointer)
@@ -217,7 +218,8 @@ class FlatGrads:
             chunk = self.flat[lo:hi]
             # from a hook: the communicator of the stream that produced the range; after backward: the step stream's
             dist.all_reduce(chunk, group=comm_of("encoder" if after_backward else self._range_branch[k]))
-            chunk.mul_(1.0 / world_size())
+            if not self.scale_in_optimizer:        # (the flat Adam kernel multiplies by 1 / world as it reads the sums)
+                chunk.mul_(1.0 / world_size())
 
     def finish(self):
         """After backward (autograd has joined every stream it used with the current one): launch what the hooks did
@@ -307,6 +309,8 @@ class TrainEngine:
             self._hi = [self.masters[id(p)] for p in self._lo]
         self.flat = FlatGrads(self.opt_params, n_chunks, align=128 if self.flat_adam else 1) \
             if (collectives_on() or self.flat_adam) else None
+        if self.flat is not None and self.flat_adam and collectives_on() and OVERLAP_ALLREDUCE:
+            self.flat.scale_in_optimizer = True        # .grad holds the SUM over ranks; the optimizer kernel divides
         if self.flat is not None and collectives_on() and OVERLAP_ALLREDUCE:
             # gradient exchange overlapped with backward, one range per (branch of the step, dtype class)
             names = {id(p): n for n, p in model.named_parameters()}
@@ -394,9 +398,10 @@ class TrainEngine:
         g = self.optimizer.param_groups[0]
         with torch.no_grad():
             self.adam_state[0] += 1
-        call("ppea_adam_flat_f32", ptr(self.P), ptr(self.flat.flat), ptr(self.M), ptr(self.V),
+        gscale = 1.0 / world_size() if (self.flat.scale_in_optimizer and collectives_on()) else 1.0
+        call("ppea_adam_flat_scaled_f32", ptr(self.P), ptr(self.flat.flat), ptr(self.M), ptr(self.V),
              ptr(self.W16) if self.n_lo else None, self.flat.numel, self.n_lo, ptr(self.adam_state),
-             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), stream_ptr())
+             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), gscale, stream_ptr())
 
     # ---- learning-rate schedule --------------------------------------------------------------------------------
     # Reference: StepLR(optimizer, scheduler_step_size, 0.1) wrapped by `accelerator.prepare` (trainer.py:144, 153) and

@@ -831,7 +831,7 @@ class _SyncBnAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z1, g1, b1, rm1, rv1, z2, g2, b2, rm2, rv2, mask, r1, r2, r2_scale, act, eps, momentum, group, table,
-                sums, skip, emit):
+                sums, skip, emit, dup=False):
         z1_in = z1
         z1 = z1.contiguous()
         N, C = z1.shape[0], z1.shape[1]
@@ -878,7 +878,7 @@ class _SyncBnAct(torch.autograd.Function):
         ctx.act, ctx.r2_scale, ctx.group, ctx.world = int(act), float(r2_scale), group, world
         ctx.has = (r1 is not None, r2 is not None)
         ctx.pdt = (g1.dtype, b1.dtype, None if g2 is None else g2.dtype)
-        ctx.skip = bool(skip)
+        ctx.skip, ctx.emit, ctx.dup = bool(skip), bool(emit), bool(dup)
         ctx.set_materialize_grads(False)
         outs = [y, st]
         ctx.mark_non_differentiable(st)
@@ -887,6 +887,8 @@ class _SyncBnAct(torch.autograd.Function):
         if emit:
             outs.append(nxt)
             ctx.mark_non_differentiable(nxt)
+        if dup:
+            outs.append(y.detach())      # y again (same storage) for its second consumer: see _BnActChannel
         return tuple(outs)
 
     @staticmethod
@@ -899,14 +901,27 @@ class _SyncBnAct(torch.autograd.Function):
         if dy is None:
             dy = torch.zeros_like(z1)
         dy = dy.contiguous().to(z1.dtype)
-        dskip = rest[0] if (ctx.skip and rest and rest[0] is not None) else None
+        rest = list(rest)
+        dskip = rest.pop(0) if ctx.skip else None
+        if ctx.emit:
+            rest.pop(0)
+        dyb = rest.pop(0) if ctx.dup else None
         if dskip is not None:
             dskip = dskip.contiguous().to(z1.dtype)
+        if dyb is not None and (ctx.has[0] or ctx.has[1]):
+            dy, dyb = dy + dyb.to(z1.dtype), None             # (r1 / r2 receive dy itself: not a block's first BatchNorm)
         two = z2 is not None
         stats = _stats_array((st[0], st[1], g1f, b1f, st[2] if two else None, st[3] if two else None, g2f, b2f))
         sums = torch.empty(3, C, device=dev, dtype=_F32)
-        err = getattr(_abi.lib, f"ppea_bn_bwd_reduce_final_{sfx}")(
-            ptr(dy), ptr(z1), ptr(z2), stats, ptr(maskf), ptr(sums), ctx.act, N, C, HW, stream_ptr())
+        if dyb is not None:
+            dyb = dyb.contiguous().to(z1.dtype)
+            dym = torch.empty_like(z1)
+            err = getattr(_abi.lib, f"ppea_bn_bwd_reduce_final_dup_{sfx}")(
+                ptr(dy), ptr(dyb), ptr(dym), ptr(z1), ptr(z2), stats, ptr(maskf), ptr(sums), ctx.act, N, C, HW, stream_ptr())
+            dy = dym if err != -1 else dy + dyb
+        else:
+            err = getattr(_abi.lib, f"ppea_bn_bwd_reduce_final_{sfx}")(
+                ptr(dy), ptr(z1), ptr(z2), stats, ptr(maskf), ptr(sums), ctx.act, N, C, HW, stream_ptr())
         if err == -1:                       # large planes: per-plane partials + finalize
             partial = torch.empty(C * N * 3, device=dev, dtype=_F32)
             call(f"ppea_bn_bwd_reduce_{sfx}", ptr(dy), ptr(z1), ptr(z2), stats, ptr(maskf), ptr(partial), ctx.act, N, C,
@@ -931,18 +946,19 @@ class _SyncBnAct(torch.autograd.Function):
         db2 = dgb[0].to(ctx.pdt[2]) if (two and n[7]) else None
         dr1 = dy if ctx.has[0] else None
         dr2 = (dy if ctx.r2_scale == 1.0 else dy * ctx.r2_scale) if ctx.has[1] else None
-        return (dz1, dg1, db1, None, None, dz2, dg2, db2, None, None, None, dr1, dr2) + (None,) * 9
+        return (dz1, dg1, db1, None, None, dz2, dg2, db2, None, None, None, dr1, dr2) + (None,) * 10
 
 
 def sync_bn_act(z1, bn1, z2=None, bn2=None, mask=None, r1=None, r2=None, r2_scale=1.0, act=ACT_NONE, group=None,
-                table=None, sums=None, skip=False, emit=False):
+                table=None, sums=None, skip=False, emit=False, dup=False):
     """-> (y, stats [4,C] = mean1 | invstd1 | mean2 | invstd2 of the global batch [, z1 for the residual use when `skip`]
-    [, the next BatchNorm's gather table with this rank's statistics of y filled in when `emit`]).  `table`: such a table
+    [, the next BatchNorm's gather table with this rank's statistics of y filled in when `emit`] [, y again for its second
+    consumer when `dup`]).  `table`: such a table
     from the launch that produced z1.  Updates the running statistics of bn1 / bn2."""
     return _SyncBnAct.apply(z1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, z2,
                             None if bn2 is None else bn2.weight, None if bn2 is None else bn2.bias,
                             None if bn2 is None else bn2.running_mean, None if bn2 is None else bn2.running_var,
-                            mask, r1, r2, r2_scale, act, bn1.eps, bn1.momentum, group, table, sums, skip, emit)
+                            mask, r1, r2, r2_scale, act, bn1.eps, bn1.momentum, group, table, sums, skip, emit, dup)
 
 
 def bn_act_apply(z1, g1, b1, mean1, invstd1, z2=None, g2=None, b2=None, mean2=None, invstd2=None, mask=None,

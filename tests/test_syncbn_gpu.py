@@ -197,6 +197,57 @@ def test_sync_bn_chain_equals_the_one_rank_chain(device, monkeypatch, dtype):
         assert rel_err(gw * world, ref_bn.weight.grad) < tol_b
 
 
+@pytest.mark.parametrize("chained", [True, False])
+def test_sync_bn_second_consumer_gradient_is_merged_in_the_reduce_launch(device, monkeypatch, chained):
+    """The BatchNorm output that feeds a block's first 1x1 conv AND its adapter: with BN_DUP the two gradients reach the
+    backward separately and the reduce launch merges them (round(dy + dyb), stored for the apply launch) -- bit-identical
+    to autograd's own element-wise add in front of the two launches, on every simulated rank."""
+    from ppeadepth import batchnorm, ops
+    from ppeadepth.batchnorm import fused_bn_act, fused_bn_act_next, second_use
+    world, n, C, H, W = 2, 3, 64, 12, 40
+    N = n * world
+    g = _g(9)
+    dt = torch.bfloat16
+    z = (torch.randn(N, C, H, W, generator=g) * 2 + 0.5).to(dt).to(device)
+    x = torch.randn(N, C, H, W, generator=g).to(dt).to(device)
+    ga, gb, gs = (torch.randn(N, C, H, W, generator=g).to(dt).to(device) for _ in range(3))
+    bnA, bnB = _mk_bn(C, device, g, False), _mk_bn(C, device, g, False)
+
+    def run(a, b, sl):
+        leaves = [t[sl].clone().requires_grad_(True) for t in (z, x)]
+        if chained:
+            y, y2 = fused_bn_act_next(leaves[0] * 1, a, b, r1=leaves[1])
+        else:
+            y2, y = fused_bn_act(leaves[0] * 1, b, skip=True)
+        first, second = y2, second_use(y2)
+        ((first.float() * ga[sl].float()).sum() + (second.float() * gb[sl].float()).sum()
+         + (y.float() * gs[sl].float()).sum()).backward()
+        return [l.grad for l in leaves] + [b.weight.grad.clone(), b.bias.grad.clone()]
+
+    res = {}
+    for dup in (False, True):
+        monkeypatch.setattr(batchnorm, "BN_DUP", dup)
+        rep = Replay(world)
+        rep.install(monkeypatch)
+        for _ in range(5):
+            rep.begin_pass()
+            outs = []
+            for r in range(world):
+                rep.begin_rank(r)
+                a, b = _copy_bn(bnA, True), _copy_bn(bnB, True)
+                ops.SYNC_COUNTERS = {}
+                outs.append(run(a, b, slice(r * n, (r + 1) * n)) + [dict(ops.SYNC_COUNTERS)])
+                ops.SYNC_COUNTERS = None
+        res[dup] = outs
+    for r in range(world):
+        for k, (u, v) in enumerate(zip(res[False][r][:-1], res[True][r][:-1])):
+            if k == 1 and not chained:
+                assert u is None and v is None                    # (x is not an input of the unchained form)
+            else:
+                assert u is not None and torch.equal(u, v), k
+        assert res[False][r][-1] == res[True][r][-1]              # same launches of ours, same collectives
+
+
 def test_sync_bn_statistics_from_the_gemm_epilogue(device, monkeypatch):
     """Stages 0 / 1: the 1x1 conv's epilogue leaves per-channel partial sums; with several ranks they become the wire-format
     local statistics in one tiny launch (no pass over the activation)."""
