@@ -16,4 +16,6 @@ python3 bench.py --no_cpu_baseline --input_pipeline > $OUT/${R}_bench_n1_input_p
 python3 tools/render_parity.py > $OUT/${R}_bf16_render_parity.txt 2>> $OUT/cfg.err || exit 1
 python3 tools/dwconv_phases.py 2>/dev/null | grep -v amdgpu > $OUT/${R}_dwconv_phases.txt
 (cd tools && python3 bench_dwbn.py 2>/dev/null | grep -v amdgpu > ../$OUT/${R}_dwconv_fused_bn.txt)
+(echo "# row-band kernels only (PPEA_DW_BM=0)"; PPEA_DW_BM=0 python3 tools/bench_dwconv.py --dtype bf16 2>/dev/null | grep -v amdgpu;
+ echo "# default dispatch (batch-major variant on the 24 / 12 / 6-row maps, and for the 48-row data gradient)"; python3 tools/bench_dwconv.py --dtype bf16 2>/dev/null | grep -v amdgpu) > $OUT/${R}_dwconv_shapes.txt
 echo evidence done

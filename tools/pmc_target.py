@@ -17,6 +17,13 @@ ws = torch.randn(128, 1, 5, 5, device=dev) / 5
 for _ in range(4):
     yb, ys = ops.dwconv_lk(x, wb, ws)
     torch.autograd.grad((yb, ys), x, (torch.ones_like(yb), torch.ones_like(ys)))
+# stage 2: the batch-major variant (dwconv_bm_kernel<27,5,...>) forward and data gradient
+x2 = torch.randn(B, 512, 12, 40, device=dev).bfloat16().requires_grad_(True)
+wb2 = torch.randn(512, 1, 27, 27, device=dev) / 27
+ws2 = torch.randn(512, 1, 5, 5, device=dev) / 5
+for _ in range(4):
+    yb, ys = ops.dwconv_lk(x2, wb2, ws2)
+    torch.autograd.grad((yb, ys), x2, (torch.ones_like(yb), torch.ones_like(ys)))
 for (K, H, W, M) in [(512, 12, 40, 512), (2048, 12, 40, 512), (512, 12, 40, 2048), (128, 48, 160, 128)]:
     xx = torch.randn(B, K, H, W, device=dev).bfloat16()
     a = (torch.randn(M, K, device=dev) / K ** 0.5).bfloat16()
