@@ -10,6 +10,7 @@
 // Statistics are combined with Chan's parallel-variance formula (per-plane two-pass sums), so there
 // is no E[x^2] - mean^2 cancellation.  Layout NCHW, T = float or bf16 (fp32 math).
 #include "bn_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(TPB) void bn_apply(const T* __restrict__ z1, const 
         for (int k = 0; k < V; ++k) {
             float u = a1 * x1[k] + o1;
             if (z2 != nullptr) u += a2 * x2[k] + o2;
-            float v = act_fwd(u, act) * m;
+            float v = act_fwd<T>(u, act) * m;
             if (r1 != nullptr) v += q1[k];
             if (r2 != nullptr) v += r2_scale * q2[k];
             o[k] = v;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(TPB) void bn_apply(const T* __restrict__ z1, const 
     for (int i = iv + threadIdx.x; i < i1; i += TPB) {
         float u = a1 * ld_f32<T>(z1 + base + i) + o1;
         if (z2 != nullptr) u += a2 * ld_f32<T>(z2 + base + i) + o2;
-        float v = act_fwd(u, act) * m;
+        float v = act_fwd<T>(u, act) * m;
         if (r1 != nullptr) v += ld_f32<T>(r1 + base + i);
         if (r2 != nullptr) v += r2_scale * ld_f32<T>(r2 + base + i);
         st_f32<T>(y + base + i, v);
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce(const T* __restrict__ dy, c
             float u = a1 * x1[k] + o1;
             float xx2 = 0.f;
             if (z2 != nullptr) { xx2 = x2[k]; u += a2 * xx2 + o2; }
-            const float g = d[k] * m * act_bwd(u, act);
+            const float g = d[k] * m * act_bwd<T>(u, act);
             sg += g;
             s1 += g * (x1[k] - mu1) * is1;
             s2 += g * (xx2 - mu2) * is2;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce(const T* __restrict__ dy, c
         float u = a1 * x1 + o1;
         float x2 = 0.f;
         if (z2 != nullptr) { x2 = ld_f32<T>(z2 + base + i); u += a2 * x2 + o2; }
-        const float g = ld_f32<T>(dy + base + i) * m * act_bwd(u, act);
+        const float g = ld_f32<T>(dy + base + i) * m * act_bwd<T>(u, act);
         sg += g;
         s1 += g * (x1 - mu1) * is1;
         s2 += g * (x2 - mu2) * is2;
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply(const T* __restrict__ dy, co
             float u = a1 * x1[k] + o1;
             float xx2 = 0.f;
             if (z2 != nullptr) { xx2 = x2[k]; u += a2 * xx2 + o2; }
-            const float g = d[k] * m * act_bwd(u, act);
+            const float g = d[k] * m * act_bwd<T>(u, act);
             o1v[k] = a1 * (g - mg - (x1[k] - mu1) * is1 * m1);
             o2v[k] = a2 * (g - mg - (xx2 - mu2) * is2 * m2);
         }
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply(const T* __restrict__ dy, co
         float u = a1 * x1 + o1;
         float x2 = 0.f;
         if (z2 != nullptr) { x2 = ld_f32<T>(z2 + base + i); u += a2 * x2 + o2; }
-        const float g = ld_f32<T>(dy + base + i) * m * act_bwd(u, act);
+        const float g = ld_f32<T>(dy + base + i) * m * act_bwd<T>(u, act);
         st_f32<T>(dz1 + base + i, a1 * (g - mg - (x1 - mu1) * is1 * m1));
         if (z2 != nullptr) st_f32<T>(dz2 + base + i, a2 * (g - mg - (x2 - mu2) * is2 * m2));
     }
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_wave(const T* __restrict__ 
             float u = a1 * x1[k] + o1;
             float xx2 = 0.f;
             if (z2 != nullptr) { xx2 = x2[k]; u += a2 * xx2 + o2; }
-            const float g = d[k] * m * act_bwd(u, act);
+            const float g = d[k] * m * act_bwd<T>(u, act);
             sg += g;
             s1 += g * (x1[k] - mu1) * is1;
             s2 += g * (xx2 - mu2) * is2;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_channel(const T* __restrict
             float u2 = a1 * x1[k] + o1;
             float xx2 = 0.f;
             if (z2 != nullptr) { xx2 = x2[k]; u2 += a2 * xx2 + o2; }
-            const float g = d[k] * m * act_bwd(u2, act);
+            const float g = d[k] * m * act_bwd<T>(u2, act);
             sg += g;
             s1 += g * (x1[k] - mu1) * is1;
             s2 += g * (xx2 - mu2) * is2;
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_channel(const T* __restrict
 // and bn_bwd_reduce_channel + bn_bwd_apply_flat.
 struct FwdPrm { const float *gamma1, *beta1, *gamma2, *beta2; float *rm1, *rv1, *rm2, *rv2, *mean1, *invstd1, *mean2, *invstd2; };
 
-template <typename T, bool TWO>
+template <typename T, bool TWO, int NV>
 __global__ __launch_bounds__(TPB) void bn_fwd_channel(const T* __restrict__ z1, const T* __restrict__ z2, FwdPrm p,
                                                       float eps, float momentum, const float* __restrict__ mask,
                                                       const T* __restrict__ r1, const T* __restrict__ r2,
@@ -497,9 +498,9 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel(const T* __restrict__ z1, 
     const int c = blockIdx.x;
     const int hv = HW / V, total = N * hv;
     const float cnt = (float)N * (float)HW;
-    float x1[CH_VECS][V], x2[TWO ? CH_VECS : 1][V];
+    float x1[NV][V], x2[TWO ? NV : 1][V];
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int j = threadIdx.x + u * TPB;
         if (j < total) {
             const int n = j / hv, i = j - n * hv;
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel(const T* __restrict__ z1, 
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u)
+    for (int u = 0; u < NV; ++u)
 #pragma unroll
         for (int k = 0; k < V; ++k) { s1 += x1[u][k]; if constexpr (TWO) s2 += x2[u][k]; }
     const float mu1 = block_sum(s1, red) / cnt;
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel(const T* __restrict__ z1, 
     if constexpr (TWO) mu2 = block_sum(s2, red) / cnt;
     float q1 = 0.f, q2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u)
+    for (int u = 0; u < NV; ++u)
         if (threadIdx.x + u * TPB < total) {
 #pragma unroll
             for (int k = 0; k < V; ++k) {
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel(const T* __restrict__ z1, 
     float a2 = 0.f, o2 = 0.f;
     if constexpr (TWO) { a2 = p.gamma2[c] * is2; o2 = p.beta2[c] - mu2 * a2; }
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int j = threadIdx.x + u * TPB;
         if (j >= total) break;
         const int n = j / hv, i = j - n * hv;
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel(const T* __restrict__ z1, 
         for (int k = 0; k < V; ++k) {
             float w = a1 * x1[u][k] + o1;
             if constexpr (TWO) w += a2 * x2[u][k] + o2;
-            float v = act_fwd(w, act) * m;
+            float v = act_fwd<T>(w, act) * m;
             if (r1 != nullptr) v += e1[k];
             if (r2 != nullptr) v += r2_scale * e2[k];
             o[k] = v;
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel(const T* __restrict__ z1, 
     }
 }
 
-template <typename T, bool TWO>
+template <typename T, bool TWO, int NV>
 __global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, const T* __restrict__ dyb, const T* __restrict__ z1,
                                                       const T* __restrict__ z2, Branch b1, Branch b2,
                                                       const float* __restrict__ mask, float inv_count,
@@ -586,10 +587,10 @@ __global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, 
     const float a1 = b1.gamma[c] * is1, o1 = b1.beta[c] - mu1 * a1;
     float is2 = 0.f, mu2 = 0.f, a2 = 0.f, o2 = 0.f;
     if constexpr (TWO) { is2 = b2.invstd[c]; mu2 = b2.mean[c]; a2 = b2.gamma[c] * is2; o2 = b2.beta[c] - mu2 * a2; }
-    float x1[CH_VECS][V], x2[TWO ? CH_VECS : 1][V], gq[CH_VECS][V];
+    float x1[NV][V], x2[TWO ? NV : 1][V], gq[NV][V];
     float sg = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int j = threadIdx.x + u * TPB;
         if (j < total) {
             const int n = j / hv, i = j - n * hv;
@@ -606,7 +607,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, 
         }
     }
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int j = threadIdx.x + u * TPB;
         if (j < total) {
             const float m = (mask != nullptr) ? mask[j / hv] : 1.f;
@@ -614,7 +615,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, 
             for (int k = 0; k < V; ++k) {
                 float w = a1 * x1[u][k] + o1;
                 if constexpr (TWO) w += a2 * x2[u][k] + o2;
-                const float g = gq[u][k] * m * act_bwd(w, act);
+                const float g = gq[u][k] * m * act_bwd<T>(w, act);
                 gq[u][k] = g;
                 sg += g;
                 s1 += g * (x1[u][k] - mu1) * is1;
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, 
     if (threadIdx.x == 0) { sums[c] = sg; sums[C + c] = s1; sums[2 * C + c] = s2; }
     const float mg = sg * inv_count, m1 = s1 * inv_count, m2 = s2 * inv_count;
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int j = threadIdx.x + u * TPB;
         if (j >= total) break;
         const int n = j / hv, i = j - n * hv;
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, 
 // Arithmetic, rounding points and running-statistics updates are those of the two separate launches (bit-identical results).
 struct NextPrm { const float *gammaA, *betaA, *gammaB, *betaB; float *rmA, *rvA, *rmB, *rvB, *meanA, *invstdA, *meanB, *invstdB; };
 
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(TPB) void bn_fwd_channel_next(const T* __restrict__ z, NextPrm p, float eps, float momentum,
                                                            const float* __restrict__ mask, const T* __restrict__ r1,
                                                            const T* __restrict__ r2, float r2_scale, T* __restrict__ y,
@@ -666,9 +667,9 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel_next(const T* __restrict__
     const int c = blockIdx.x;
     const int hv = HW / V, total = N * hv;
     const float cnt = (float)N * (float)HW;
-    float x[CH_VECS][V];
+    float x[NV][V];
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int j = threadIdx.x + u * TPB;
         if (j < total) {
             const int n = j / hv, i = j - n * hv;
@@ -682,13 +683,13 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel_next(const T* __restrict__
     auto stats = [&](float& mu, float& q) {
         float s = 0.f;
 #pragma unroll
-        for (int u = 0; u < CH_VECS; ++u)
+        for (int u = 0; u < NV; ++u)
 #pragma unroll
             for (int k = 0; k < V; ++k) s += x[u][k];
         mu = block_sum(s, red) / cnt;
         float qq = 0.f;
 #pragma unroll
-        for (int u = 0; u < CH_VECS; ++u)
+        for (int u = 0; u < NV; ++u)
             if (threadIdx.x + u * TPB < total) {
 #pragma unroll
                 for (int k = 0; k < V; ++k) qq += (x[u][k] - mu) * (x[u][k] - mu);
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel_next(const T* __restrict__
     }
     const float aA = p.gammaA[c] * isA, oA = p.betaA[c] - muA * aA;
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int j = threadIdx.x + u * TPB;
         if (j < total) {
             const int n = j / hv, i = j - n * hv;
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel_next(const T* __restrict__
     }
     const float aB = p.gammaB[c] * isB, oB = p.betaB[c] - muB * aB;
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int j = threadIdx.x + u * TPB;
         if (j < total) {
             const int n = j / hv, i = j - n * hv;
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel_next(const T* __restrict__
 }
 
 // sums [4][C] = d betaA | d gammaA | d betaB | d gammaB
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(TPB) void bn_bwd_channel_next(const T* __restrict__ dy2, const T* __restrict__ dy2b, const T* __restrict__ dskip,
                                                            const T* __restrict__ z, const T* __restrict__ y, Branch A,
                                                            Branch B, const float* __restrict__ mask, float inv_count,
@@ -762,10 +763,10 @@ __global__ __launch_bounds__(TPB) void bn_bwd_channel_next(const T* __restrict__
     const int hv = HW / V, total = N * hv;
     const float isA = A.invstd[c], muA = A.mean[c], aA = A.gamma[c] * isA;
     const float isB = B.invstd[c], muB = B.mean[c], aB = B.gamma[c] * isB;
-    float g[CH_VECS][V], xd[CH_VECS][V];                    // gradient in flight, input - mean of the current BN
+    float g[NV][V], xd[NV][V];                    // gradient in flight, input - mean of the current BN
     float sg = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int j = threadIdx.x + u * TPB;
         if (j < total) {
             const int n = j / hv, i = j - n * hv;
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_channel_next(const T* __restrict__
     float mg = sg * inv_count, m1 = s1 * inv_count;
     sg = 0.f; s1 = 0.f;
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int j = threadIdx.x + u * TPB;
         if (j < total) {
             const int n = j / hv, i = j - n * hv;
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_channel_next(const T* __restrict__
     if (threadIdx.x == 0) { sums[c] = sg; sums[C + c] = s1; }
     mg = sg * inv_count; m1 = s1 * inv_count;
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int j = threadIdx.x + u * TPB;
         if (j < total) {
             const int n = j / hv, i = j - n * hv;
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_flat(const T* __restrict__ z1, c
     for (int k = 0; k < V; ++k) {
         float u = a1 * x1[k] + o1;
         if (z2 != nullptr) u += a2 * x2[k] + o2;
-        float v = act_fwd(u, act) * m;
+        float v = act_fwd<T>(u, act) * m;
         if (r1 != nullptr) v += q1[k];
         if (r2 != nullptr) v += r2_scale * q2[k];
         o[k] = v;
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_flat(const T* __restrict__ d
         float u = a1 * x1[k] + o1;
         float xx2 = 0.f;
         if (z2 != nullptr) { xx2 = x2[k]; u += a2 * xx2 + o2; }
-        const float g = d[k] * m * act_bwd(u, act);
+        const float g = d[k] * m * act_bwd<T>(u, act);
         o1v[k] = a1 * (g - mg - (x1[k] - mu1) * is1 * m1);
         o2v[k] = a2 * (g - mg - (xx2 - mu2) * is2 * m2);
     }
@@ -1036,6 +1037,15 @@ int bwd_reduce_final_impl(const void* dy, const void* dyb, void* dym, const void
     return launch_status();
 }
 
+// Vectors per thread of a channel-owning workgroup: the kernels keep the channel in registers, NV x 8 values per array and
+// thread -- sized for the channel at hand (12 x 40 planes at batch 12: 3, not the 8 of the 16384-element limit) the register
+// count lets 8 workgroups share a CU instead of 3, and their load / reduce / store phases overlap.
+#define PPEA_BN_NV(nv_, LAUNCH_)                                                                   \
+    do {                                                                                          \
+        if ((nv_) <= 1) { LAUNCH_(1); } else if ((nv_) == 2) { LAUNCH_(2); } else if ((nv_) == 3) { LAUNCH_(3); }   \
+        else if ((nv_) == 4) { LAUNCH_(4); } else { LAUNCH_(8); }                                  \
+    } while (0)
+static inline int bn_nv(int N, int HW) { return (int)(((long)N * (HW / V) + TPB - 1) / TPB); }
 template <typename T>
 int fwd_channel_impl(const void* z1, const void* z2, const float* const* prm, float* const* outp, float eps, float momentum,
                      const float* mask, const void* r1, const void* r2, float r2_scale, void* y, int act, int N, int C, int HW,
@@ -1043,12 +1053,15 @@ int fwd_channel_impl(const void* z1, const void* z2, const float* const* prm, fl
     if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS || act < 0 || act > 2)
         return PPEA_ERR_UNSUPPORTED;
     FwdPrm p{prm[0], prm[1], prm[2], prm[3], outp[0], outp[1], outp[2], outp[3], outp[4], outp[5], outp[6], outp[7]};
-    if (z2 != nullptr)
-        hipLaunchKernelGGL((bn_fwd_channel<T, true>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)z1,
-                           (const T*)z2, p, eps, momentum, mask, (const T*)r1, (const T*)r2, r2_scale, (T*)y, act, N, C, HW);
-    else
-        hipLaunchKernelGGL((bn_fwd_channel<T, false>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)z1,
-                           (const T*)nullptr, p, eps, momentum, mask, (const T*)r1, (const T*)r2, r2_scale, (T*)y, act, N, C, HW);
+#define PPEA_L(NV_)                                                                                                   \
+    if (z2 != nullptr)                                                                                                \
+        hipLaunchKernelGGL((bn_fwd_channel<T, true, NV_>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, \
+                           (const T*)z1, (const T*)z2, p, eps, momentum, mask, (const T*)r1, (const T*)r2, r2_scale, (T*)y, act, N, C, HW); \
+    else                                                                                                              \
+        hipLaunchKernelGGL((bn_fwd_channel<T, false, NV_>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, \
+                           (const T*)z1, (const T*)nullptr, p, eps, momentum, mask, (const T*)r1, (const T*)r2, r2_scale, (T*)y, act, N, C, HW)
+    PPEA_BN_NV(bn_nv(N, HW), PPEA_L);
+#undef PPEA_L
     return launch_status();
 }
 template <typename T>
@@ -1058,12 +1071,15 @@ int bwd_channel_impl(const void* dy, const void* dyb, const void* z1, const void
     if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS || act < 0 || act > 2)
         return PPEA_ERR_UNSUPPORTED;
     Branch b1{st[0], st[1], st[2], st[3]}, b2{st[4], st[5], st[6], st[7]};
-    if (z2 != nullptr)
-        hipLaunchKernelGGL((bn_bwd_channel<T, true>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy, (const T*)dyb,
-                           (const T*)z1, (const T*)z2, b1, b2, mask, inv_count, (const T*)acc, (T*)dz1, (T*)dz2, sums, act, N, C, HW);
-    else
-        hipLaunchKernelGGL((bn_bwd_channel<T, false>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy, (const T*)dyb,
-                           (const T*)z1, (const T*)nullptr, b1, b2, mask, inv_count, (const T*)acc, (T*)dz1, (T*)nullptr, sums, act, N, C, HW);
+#define PPEA_L(NV_)                                                                                                   \
+    if (z2 != nullptr)                                                                                                \
+        hipLaunchKernelGGL((bn_bwd_channel<T, true, NV_>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, \
+                           (const T*)dy, (const T*)dyb, (const T*)z1, (const T*)z2, b1, b2, mask, inv_count, (const T*)acc, (T*)dz1, (T*)dz2, sums, act, N, C, HW); \
+    else                                                                                                              \
+        hipLaunchKernelGGL((bn_bwd_channel<T, false, NV_>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, \
+                           (const T*)dy, (const T*)dyb, (const T*)z1, (const T*)nullptr, b1, b2, mask, inv_count, (const T*)acc, (T*)dz1, (T*)nullptr, sums, act, N, C, HW)
+    PPEA_BN_NV(bn_nv(N, HW), PPEA_L);
+#undef PPEA_L
     return launch_status();
 }
 
@@ -1073,8 +1089,11 @@ int fwd_channel_next_impl(const void* z, const float* const* prm, float* const* 
                           int HW, void* stream) {
     if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS) return PPEA_ERR_UNSUPPORTED;
     NextPrm p{prm[0], prm[1], prm[2], prm[3], outp[0], outp[1], outp[2], outp[3], outp[4], outp[5], outp[6], outp[7]};
-    hipLaunchKernelGGL(bn_fwd_channel_next<T>, dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)z, p, eps,
-                       momentum, mask, (const T*)r1, (const T*)r2, r2_scale, (T*)y, (T*)y2, N, C, HW);
+#define PPEA_L(NV_)                                                                                                   \
+    hipLaunchKernelGGL((bn_fwd_channel_next<T, NV_>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)z, p, eps, \
+                       momentum, mask, (const T*)r1, (const T*)r2, r2_scale, (T*)y, (T*)y2, N, C, HW)
+    PPEA_BN_NV(bn_nv(N, HW), PPEA_L);
+#undef PPEA_L
     return launch_status();
 }
 template <typename T>
@@ -1083,8 +1102,11 @@ int bwd_channel_next_impl(const void* dy2, const void* dy2b, const void* dskip, 
                           void* stream) {
     if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS) return PPEA_ERR_UNSUPPORTED;
     Branch A{st[0], st[1], st[2], st[3]}, B{st[4], st[5], st[6], st[7]};
-    hipLaunchKernelGGL(bn_bwd_channel_next<T>, dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy2, (const T*)dy2b,
-                       (const T*)dskip, (const T*)z, (const T*)y, A, B, mask, inv_count, (T*)dz, (T*)dy, sums, N, C, HW);
+#define PPEA_L(NV_)                                                                                                   \
+    hipLaunchKernelGGL((bn_bwd_channel_next<T, NV_>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)dy2, \
+                       (const T*)dy2b, (const T*)dskip, (const T*)z, (const T*)y, A, B, mask, inv_count, (T*)dz, (T*)dy, sums, N, C, HW)
+    PPEA_BN_NV(bn_nv(N, HW), PPEA_L);
+#undef PPEA_L
     return launch_status();
 }
 

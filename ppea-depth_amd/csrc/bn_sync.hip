@@ -199,7 +199,7 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel_sync(const T* __restrict__
             for (int k = 0; k < V; ++k) {
                 float w = a1 * x1[u][k] + o1;
                 if constexpr (TWO) w += a2 * x2[u][k] + o2;
-                float v = act_fwd(w, act) * m;
+                float v = act_fwd<T>(w, act) * m;
                 if (r1 != nullptr) v += e1[k];
                 if (r2 != nullptr) v += r2_scale * e2[k];
                 o[k] = v;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_flat_sync(const T* __restrict__ 
     for (int k = 0; k < V; ++k) {
         float u = a1 * x1[k] + o1;
         if (z2 != nullptr) u += a2 * x2[k] + o2;
-        float v = act_fwd(u, act) * m;
+        float v = act_fwd<T>(u, act) * m;
         if (r1 != nullptr) v += q1[k];
         if (r2 != nullptr) v += r2_scale * q2[k];
         o[k] = v;

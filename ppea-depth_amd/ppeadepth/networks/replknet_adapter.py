@@ -404,11 +404,14 @@ class ConvFFN(nn.Module):
                 out, x = fused_bn_act(x, self.preffn_bn, skip=True)    # x: the same tensor, routed for the residual use
             adpt, join = None, None
             if self.test_id >= 0:
-                a_in = second_use(out)       # an alias of `out`: its gradient joins pw1's inside the BatchNorm's backward launch
                 if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
-                    adpt, join = _forked_adapter(self.mlp_adapter, a_in)
+                    adpt, join = _forked_adapter(self.mlp_adapter, out)
                 else:
-                    adpt = self.mlp_adapter(a_in)
+                    # in line: hand the adapter the alias of `out` whose gradient joins pw1's inside the BatchNorm's backward
+                    # launch (batchnorm.second_use).  NOT for the forked adapter: with the alias's gradient produced on the side
+                    # stream, replayed hipGraphs of the fp32 step gave wrong encoder gradients in 2 of 3 captures (eager steps
+                    # and the in-line form never did; cause not found)
+                    adpt = self.mlp_adapter(second_use(out))
             z1, s1 = _conv_sums(self.pw1.conv, out)
             h = fused_bn_act(z1, self.pw1.bn, act=ops.ACT_GELU, sums=s1)
             z, s2 = _conv_sums(self.pw2.conv, h)
@@ -485,11 +488,10 @@ class RepLKBlock(nn.Module):
                 out, x = fused_bn_act(x, self.prelkb_bn, skip=True)    # x: the same tensor, routed for the residual use
             adpt, join = None, None
             if self.test_id >= 0:
-                a_in = second_use(out)       # (see ConvFFN.forward)
                 if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
-                    adpt, join = _forked_adapter(self.adapter, a_in)
+                    adpt, join = _forked_adapter(self.adapter, out)
                 else:
-                    adpt = self.adapter(a_in)
+                    adpt = self.adapter(second_use(out))         # (see ConvFFN.forward)
             t = self._pw1_large_kernel_fused(out)
             if t is None:
                 t = self.large_kernel.forward_act(self.pw1(out), ops.ACT_RELU)

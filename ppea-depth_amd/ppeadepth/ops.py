@@ -616,6 +616,17 @@ def _ptr_array(ts):
     return arr
 
 
+def _other_stream_grad(g):
+    """A gradient that may have been produced on ANOTHER stream (the second consumer of a BatchNorm output is the block's
+    adapter, which runs on a forked side stream) and is read by a kernel launched here: mark it as in use by the current
+    stream.  The autograd engine makes the consumer stream wait for the producer, but for a gradient that is not accumulated
+    with another one it does not record the consumer on the tensor -- the block would go back to the producer stream's pool
+    as soon as this backward returns and could be rewritten by that stream's next allocation while the kernel launched here
+    has not run yet (seen as wrong encoder gradients in replayed hipGraphs, where such a reuse is baked in)."""
+    if g is not None and g.is_cuda:
+        g.record_stream(torch.cuda.current_stream())
+
+
 class _BnActChannel(torch.autograd.Function):
     """y = act(BN1(z1) [+ BN2(z2)]) [* mask[n]] [+ r1] [+ s * r2] with batch statistics, running-statistics update and
     the saved (mean, invstd) in ONE launch; backward (sums + dz) in one launch."""
@@ -666,6 +677,7 @@ class _BnActChannel(torch.autograd.Function):
         z1, z2, st, g1f, b1f, g2f, b2f, maskf = ctx.saved_tensors
         N, C = z1.shape[0], z1.shape[1]
         HW = z1.numel() // (N * C)
+        _other_stream_grad(dyb)
         if dy is None:
             dy, dyb = (dyb, None) if dyb is not None else (torch.zeros_like(z1), None)
         dy = dy.contiguous().to(z1.dtype)
@@ -743,6 +755,7 @@ class _BnActChannelNext(torch.autograd.Function):
         z, y, st, gAf, bAf, gBf, bBf, maskf = ctx.saved_tensors
         N, C = z.shape[0], z.shape[1]
         HW = z.numel() // (N * C)
+        _other_stream_grad(dy2b)
         if dy2 is None:
             dy2, dy2b = (dy2b, None) if dy2b is not None else (torch.zeros_like(z), None)
         dy2 = dy2.contiguous().to(z.dtype)
@@ -751,7 +764,8 @@ class _BnActChannelNext(torch.autograd.Function):
         dz, dyt = torch.empty_like(z), torch.empty_like(z)
         stats = _stats_array((st[0], st[1], gAf, bAf, st[2], st[3], gBf, bBf))
         if dy2b is not None:
-            call(f"ppea_bn_bwd_channel_next_dup_{_suffix(z)}", ptr(dy2), ptr(dy2b.contiguous().to(z.dtype)), ptr(dskip), ptr(z),
+            dy2b = dy2b.contiguous().to(z.dtype)
+            call(f"ppea_bn_bwd_channel_next_dup_{_suffix(z)}", ptr(dy2), ptr(dy2b), ptr(dskip), ptr(z),
                  ptr(y), stats, ptr(maskf), 1.0 / float(N * HW), ptr(dz), ptr(dyt), ptr(sums), N, C, HW, stream_ptr())
         else:
             call(f"ppea_bn_bwd_channel_next_{_suffix(z)}", ptr(dy2), ptr(dskip), ptr(z), ptr(y), stats, ptr(maskf),
@@ -908,6 +922,7 @@ class _SyncBnAct(torch.autograd.Function):
         dyb = rest.pop(0) if ctx.dup else None
         if dskip is not None:
             dskip = dskip.contiguous().to(z1.dtype)
+        _other_stream_grad(dyb)
         if dyb is not None and (ctx.has[0] or ctx.has[1]):
             dy, dyb = dy + dyb.to(z1.dtype), None             # (r1 / r2 receive dy itself: not a block's first BatchNorm)
         two = z2 is not None

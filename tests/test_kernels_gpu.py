@@ -1171,8 +1171,10 @@ def test_block_chain_last_bn_plus_next_pre_bn_is_bit_identical(device, dtype="bf
         assert torch.equal(a[3][n], b[3][n]), n
 
 
+@pytest.mark.parametrize("dtype,shape", [("bf16", (128, 13, 12, 20, 3)), ("f32", (128, 13, 12, 20, 3)), ("f32", (64, 27, 12, 40, 5)),
+                                         ("bf16", (64, 27, 12, 40, 12))])
 @pytest.mark.parametrize("chain", [True, False])
-def test_bn_second_consumer_gradient_added_in_the_backward_launch_is_bit_identical(device, chain):
+def test_bn_second_consumer_gradient_added_in_the_backward_launch_is_bit_identical(device, chain, dtype, shape):
     """A block's first BatchNorm output feeds its first 1x1 conv and its adapter.  With BN_DUP the adapter reads an alias whose
     gradient reaches the BatchNorm's backward launch separately and is added there (round(dy + dyb), then the usual
     arithmetic) instead of by autograd's own element-wise kernel: a whole stage must agree BITWISE with and without it --
@@ -1181,11 +1183,12 @@ def test_bn_second_consumer_gradient_added_in_the_backward_launch_is_bit_identic
     from torch.profiler import ProfilerActivity, profile
     from ppeadepth import batchnorm, rng
     from ppeadepth.networks import replknet_adapter as rka
-    C, K, H, W, B = 128, 13, 12, 20, 3
+    C, K, H, W, B = shape
 
     def run(dup):
-        saved = (batchnorm.BN_DUP, batchnorm.BN_CHAIN)
+        saved = (batchnorm.BN_DUP, batchnorm.BN_CHAIN, rka.ADAPTER_STREAMS)
         batchnorm.BN_DUP, batchnorm.BN_CHAIN = dup, chain
+        rka.ADAPTER_STREAMS = False            # the alias is handed to adapters that run in line (the teacher's), see rka.ConvFFN.forward
         try:
             st = rka.RepLKNetStage(C, 2, K, [0.1, 0.2], 5, adpt_test=4, ratio=0.25)
             synth.fill_state_dict(st)
@@ -1198,24 +1201,30 @@ def test_bn_second_consumer_gradient_added_in_the_backward_launch_is_bit_identic
             rng.set_mode("reference")
             torch.manual_seed(11)
             with profile(activities=[ProfilerActivity.CPU]) as prof:
-                with torch.autocast("cuda", dtype=torch.bfloat16):
-                    y = st(x.bfloat16())
-                y.backward(go.bfloat16())
+                if dtype == "bf16":
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        y = st(x.bfloat16())
+                    y.backward(go.bfloat16())
+                else:
+                    y = st(x)
+                    y.backward(go)
             torch.cuda.synchronize()
             adds = sum(1 for e in prof.events() if e.name in ("aten::add_", "aten::add"))
             grads = {n: p.grad for n, p in st.named_parameters() if p.grad is not None}
             return y.detach(), x.grad, grads, {n: b.clone() for n, b in st.named_buffers()}, adds
         finally:
-            batchnorm.BN_DUP, batchnorm.BN_CHAIN = saved
+            batchnorm.BN_DUP, batchnorm.BN_CHAIN, rka.ADAPTER_STREAMS = saved
             rng.set_mode("device")
 
     a, b = run(False), run(True)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # fp32: the adapters' convolutions run in the library, whose weight-gradient kernels do not sum in a fixed order
+    same = torch.equal if dtype == "bf16" else (lambda u, v: rel_err(u, v) < 1e-5)
+    assert same(a[0], b[0]) and same(a[1], b[1])
     assert a[2].keys() == b[2].keys() and len(a[2]) > 20
     for n in a[2]:
-        assert torch.equal(a[2][n], b[2][n]), n
+        assert same(a[2][n], b[2][n]), n
     for n in a[3]:
-        assert torch.equal(a[3][n], b[3][n]), n
+        assert same(a[3][n], b[3][n]), n
     assert b[4] <= a[4] - 3, (a[4], b[4])              # 4 blocks: at least 3 element-wise adds gone
 
 
