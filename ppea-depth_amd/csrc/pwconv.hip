@@ -248,14 +248,18 @@ __global__ __launch_bounds__(256) void pwconv_kernel(const uint16_t* __restrict_
 //   * epilogue: `v_permlane16_swap` between the packed results of two neighbouring 16-pixel tiles gives every lane 8
 //     consecutive pixels of one channel: one 16-byte store instead of two 8-byte ones (a wave writes 64 contiguous bytes
 //     per channel row).
-// Requirements: K % BK == 0, HW % 8 == 0, A row-major [M][K] (the transposed-A mode stays on v1).
+//   * TA (the matrix given transposed, At [K][M]: data gradients use the forward weight as is): with BM = 128 the A tile
+//     [BK k][128 m] has the X tile's shape, so it is staged with the X tile's source swizzle and its fragments come out of
+//     the same transposing read -- the adapters' data gradients ran 17-22 us on v1's transposed mode against 5-9 us for
+//     the same GEMM with a row-major matrix.
+// Requirements: K % BK == 0, HW % 8 == 0; TA: BM = 128, M % 8 == 0.
 constexpr int NSTAGE = 3;
 
 template <int BK> __device__ __forceinline__ int a_swz16(int row) {
     return BK == 64 ? ((row >> 1) & 7) : (2 * ((row >> 2) & 1));
 }
 
-template <int BM, int BK, int EPI>
+template <int BM, int BK, int EPI, bool TA = false>
 __global__ __launch_bounds__(256) void pwconv2_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ X,
                                                       const void* __restrict__ bias, int bias_bf16,
                                                       const uint16_t* __restrict__ aux, uint16_t* __restrict__ Y,
@@ -263,6 +267,7 @@ __global__ __launch_bounds__(256) void pwconv2_kernel(const uint16_t* __restrict
                                                       int total) {
     constexpr int WM = BM >= 64 ? 2 : 1, WN = 4 / WM;
     constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 16, NT = TN / 16;
+    static_assert(!TA || BM == 128, "the transposed-A tile reuses the X tile's 256-byte-row layout");
     constexpr int ARB = BK * 2;                          // bytes per A row
     constexpr int A_BYTES = BM * ARB, X_BYTES = BK * B_STRIDE, STAGE = A_BYTES + X_BYTES;
     constexpr int A_INS = A_BYTES / 1024 / 4, X_INS = X_BYTES / 1024 / 4;      // LDS-DMA instructions per wave and stage
@@ -287,9 +292,16 @@ __global__ __launch_bounds__(256) void pwconv2_kernel(const uint16_t* __restrict
 #pragma unroll
     for (int c = 0; c < A_INS; ++c) {
         const int t = c * 4 + wave;                              // 1-KiB piece of the A tile
-        const int row = t * (1024 / ARB) + lane / (ARB / 16), slot = lane % (ARB / 16);
-        const int m = min(m0 + row, M - 1);                      // rows past M: any valid row (their outputs are not stored)
-        a_src[c] = A + (long)m * K + 8 * (slot ^ a_swz16<BK>(row));
+        if constexpr (TA) {                                      // [BK k][128 m]: the X tile's layout and source swizzle
+            const int row = 4 * t + (lane >> 4), slot = lane & 15;
+            int m = m0 + 8 * (slot ^ (2 * (row & 3) + 8 * ((row >> 3) & 1)));
+            if (m >= M) m = m0;                                  // chunks past M: any valid chunk (not stored; M % 8 == 0)
+            a_src[c] = A + (long)row * M + m;
+        } else {
+            const int row = t * (1024 / ARB) + lane / (ARB / 16), slot = lane % (ARB / 16);
+            const int m = min(m0 + row, M - 1);                  // rows past M: any valid row (their outputs are not stored)
+            a_src[c] = A + (long)m * K + 8 * (slot ^ a_swz16<BK>(row));
+        }
     }
 #pragma unroll
     for (int c = 0; c < X_INS; ++c) {
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(256) void pwconv2_kernel(const uint16_t* __restrict
     };
     auto issue = [&](int kt, int stage) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE + wave * 1024);
-        const long ka = (long)kt * BK, kx = (long)kt * BK * HW;
+        const long ka = TA ? (long)kt * BK * M : (long)kt * BK, kx = (long)kt * BK * HW;
 #pragma unroll
         for (int c = 0; c < A_INS; ++c) glds16(a_src[c] + ka, base + c * 4096);
 #pragma unroll
@@ -350,7 +362,19 @@ __global__ __launch_bounds__(256) void pwconv2_kernel(const uint16_t* __restrict
         for (int h = 0; h < KH; ++h) {
             bf16x8 af[MT], bfr[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + a_off[i][h]));
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (TA) {
+                    const int chunk = (((wm * TM + 16 * i) >> 2) + pp) ^ b_s;
+                    const uint8_t* ap = buf + b_rowi * B_STRIDE + h * 32 * B_STRIDE + (chunk << 3);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap + 4 * B_STRIDE));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8a;
+                    const s16x8a both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    af[i] = __builtin_bit_cast(bf16x8, both);
+                } else {
+                    af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(buf + a_off[i][h]));
+                }
+            }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int chunk = (((wn * TN + 16 * j) >> 2) + pp) ^ b_s;
@@ -473,12 +497,12 @@ PwCfg pw_choose(int B, int M, int K, int HW, bool ta) {
     return c;
 }
 
-template <int BM, int BK, int EPI>
+template <int BM, int BK, int EPI, bool TA = false>
 int launch_pw2_t(const void* A, const void* X, const void* bias, int bias_bf16, const void* aux, void* Y, void* Y2, int B,
                  int M, int K, int HW, hipStream_t st) {
     constexpr int smem = NSTAGE * (BM * BK * 2 + BK * B_STRIDE);
     static bool ready = false;                                   // per instantiation
-    auto kern = pwconv2_kernel<BM, BK, EPI>;
+    auto kern = pwconv2_kernel<BM, BK, EPI, TA>;
     if (!ready) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
@@ -504,6 +528,17 @@ int launch_pw(const void* A, const void* X, const void* bias, int bias_bf16, con
             PW2(32, 64);
 #undef PW2
         }
+    }
+    if constexpr (TA) {
+        // transposed matrix on the LDS-DMA ring: 128-row tiles only (see pwconv2_kernel); PPEA_PW_V2=0 keeps v1
+        const char* v2env = getenv("PPEA_PW_V2");
+        static const bool ta_v2 = !(getenv("PPEA_PW_TA_V2") != nullptr && getenv("PPEA_PW_TA_V2")[0] == '0');
+        // ... where they give at least ~128 workgroups: a 128-channel result on 12 x 40 maps is 48 tiles with a long
+        // contraction each, and v1's 32-row tiles (192 workgroups) are faster there (10 against 18 us, tools/bench_pw_ta.py)
+        const long tiles128 = (long)((HW + BN - 1) / BN) * ((M + 127) / 128) * B;
+        if (ta_v2 && !(v2env != nullptr && v2env[0] == '0' && v2env[1] == 0) && M >= 128 && tiles128 >= 128 && (M % 8) == 0 &&
+            (K % 32) == 0)
+            return launch_pw2_t<128, 32, EPI, true>(A, X, bias, bias_bf16, aux, Y, Y2, B, M, K, HW, st);
     }
     const int nb = (HW + BN - 1) / BN;
 #define PW_LAUNCH(BM_, WM_, WN_, BK_)                                                                                 \

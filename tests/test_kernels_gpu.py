@@ -461,6 +461,33 @@ def test_pwconv_mfma(device, B, M, K, H, W):
     assert (xd.grad.float().cpu() - gref).abs().max() <= gref.abs().max() * 2 ** -7
 
 
+@pytest.mark.parametrize("epi", ["none", "dgelu"])
+@pytest.mark.parametrize("B,M,K,H,W", [(12, 128, 512, 12, 40), (3, 512, 128, 12, 40), (2, 160, 128, 24, 80), (2, 72, 96, 6, 20),
+                                       (1, 1024, 256, 5, 8), (2, 128, 1152, 12, 40)])
+def test_pwconv_transposed_matrix_on_the_lds_dma_ring(device, monkeypatch, epi, B, M, K, H, W):
+    """The transposed-A mode (At [K][M]: the adapters' and the frozen convs' data gradients use the forward matrix as is)
+    on the v2 kernel, whose A tile then has the X tile's layout and comes out of the same transposing LDS read: equal to
+    v1's transposed mode to bf16 rounding, and both to the fp32 product of the bf16 operands; ragged M (160, 72) and M
+    tiles past the matrix included."""
+    from ppeadepth import ops
+    g = _g(M + K + H)
+    x = torch.randn(B, K, H, W, generator=g).bfloat16().to(device)
+    at = (torch.randn(K, M, generator=g) / K ** 0.5).bfloat16().to(device)
+    aux = torch.randn(B, M, H, W, generator=g).bfloat16().to(device)
+    kw = dict(epi=ops.EPI_DGELU, aux=aux) if epi == "dgelu" else {}
+    ref = torch.einsum("km,bkhw->bmhw", at.float(), x.float())
+    if epi == "dgelu":
+        a = aux.float()
+        ref = ref * (0.5 * (1 + torch.erf(a / 2 ** 0.5)) + a * torch.exp(-0.5 * a * a) / (2 * torch.pi) ** 0.5)
+    monkeypatch.setenv("PPEA_PW_V2", "0")
+    y1 = ops.pwconv_ex(at, x, transposed=True, **kw)
+    monkeypatch.delenv("PPEA_PW_V2")
+    y2 = ops.pwconv_ex(at, x, transposed=True, **kw)
+    y1, y2 = (y1[0] if isinstance(y1, tuple) else y1), (y2[0] if isinstance(y2, tuple) else y2)
+    tol = ref.abs().max() * 2 ** -7
+    assert (y1.float() - ref).abs().max() <= tol and (y2.float() - ref).abs().max() <= tol
+
+
 @pytest.mark.parametrize("tile", ["128,64", "128,32", "64,64", "64,32", "32,64"])
 @pytest.mark.parametrize("B,M,K,H,W", [(2, 256, 128, 48, 160), (3, 512, 256, 12, 40), (2, 200, 192, 24, 80),
                                        (3, 96, 512, 6, 20), (1, 1024, 1024, 5, 8), (5, 64, 64, 13, 8)])
