@@ -105,4 +105,14 @@ __device__ __forceinline__ float act_bwd(float u, int act) {
     return 1.f;
 }
 
+// Vectors per thread of a channel-owning workgroup: the kernels keep the channel in registers, NV x 8 values per array and
+// thread -- sized for the channel at hand (12 x 40 planes at batch 12: 3, not the 8 of the 16384-element limit) the register
+// count lets 8 workgroups share a CU instead of 3, and their load / reduce / store phases overlap.
+#define PPEA_BN_NV(nv_, LAUNCH_)                                                                   \
+    do {                                                                                          \
+        if ((nv_) <= 1) { LAUNCH_(1); } else if ((nv_) == 2) { LAUNCH_(2); } else if ((nv_) == 3) { LAUNCH_(3); }   \
+        else if ((nv_) == 4) { LAUNCH_(4); } else { LAUNCH_(8); }                                  \
+    } while (0)
+static inline int bn_nv(int N, int HW) { return (int)(((long)N * (HW / V) + TPB - 1) / TPB); }
+
 }  // namespace

@@ -1037,15 +1037,6 @@ int bwd_reduce_final_impl(const void* dy, const void* dyb, void* dym, const void
     return launch_status();
 }
 
-// Vectors per thread of a channel-owning workgroup: the kernels keep the channel in registers, NV x 8 values per array and
-// thread -- sized for the channel at hand (12 x 40 planes at batch 12: 3, not the 8 of the 16384-element limit) the register
-// count lets 8 workgroups share a CU instead of 3, and their load / reduce / store phases overlap.
-#define PPEA_BN_NV(nv_, LAUNCH_)                                                                   \
-    do {                                                                                          \
-        if ((nv_) <= 1) { LAUNCH_(1); } else if ((nv_) == 2) { LAUNCH_(2); } else if ((nv_) == 3) { LAUNCH_(3); }   \
-        else if ((nv_) == 4) { LAUNCH_(4); } else { LAUNCH_(8); }                                  \
-    } while (0)
-static inline int bn_nv(int N, int HW) { return (int)(((long)N * (HW / V) + TPB - 1) / TPB); }
 template <typename T>
 int fwd_channel_impl(const void* z1, const void* z2, const float* const* prm, float* const* outp, float eps, float momentum,
                      const float* mask, const void* r1, const void* r2, float r2_scale, void* y, int act, int N, int C, int HW,

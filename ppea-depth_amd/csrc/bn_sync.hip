@@ -46,16 +46,16 @@ __device__ __forceinline__ void chan_combine(const Gathered g, int off, int C, i
 struct SyncPrm { const float *gamma1, *beta1, *gamma2, *beta2; float *rm1, *rv1, *rm2, *rv2, *mean1, *invstd1, *mean2, *invstd2; };
 
 // ---- local statistics in wire format, one workgroup per channel (N * HW <= 16384) ----------------------------------------
-template <typename T, bool TWO>
+template <typename T, bool TWO, int NV>
 __global__ __launch_bounds__(TPB) void bn_stats_channel_pk(const T* __restrict__ z1, const T* __restrict__ z2,
                                                            float* __restrict__ packed, int N, int C, int HW) {
     __shared__ float red[4];
     const int c = blockIdx.x;
     const int hv = HW / V, total = N * hv;
     const float cnt = (float)N * (float)HW;
-    float x1[CH_VECS][V], x2[TWO ? CH_VECS : 1][V];
+    float x1[NV][V], x2[TWO ? NV : 1][V];
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int j = threadIdx.x + u * TPB;
         if (j < total) {
             const int n = j / hv, i = j - n * hv;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(TPB) void bn_stats_channel_pk(const T* __restrict__
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u)
+    for (int u = 0; u < NV; ++u)
 #pragma unroll
         for (int k = 0; k < V; ++k) { s1 += x1[u][k]; if constexpr (TWO) s2 += x2[u][k]; }
     const float mu1 = block_sum(s1, red) / cnt;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(TPB) void bn_stats_channel_pk(const T* __restrict__
     if constexpr (TWO) mu2 = block_sum(s2, red) / cnt;
     float q1 = 0.f, q2 = 0.f;
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u)
+    for (int u = 0; u < NV; ++u)
         if (threadIdx.x + u * TPB < total) {
 #pragma unroll
             for (int k = 0; k < V; ++k) {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void bn_sums_to_packed(const float* __restrict
 }
 
 // ---- combine + apply, one workgroup per channel; EMIT: also the local statistics of the stored values ---------------------
-template <typename T, bool TWO, bool EMIT>
+template <typename T, bool TWO, bool EMIT, int NV>
 __global__ __launch_bounds__(TPB) void bn_fwd_channel_sync(const T* __restrict__ z1, const T* __restrict__ z2, Gathered g,
                                                            SyncPrm p, float eps, float momentum, const float* __restrict__ mask,
                                                            const T* __restrict__ r1, const T* __restrict__ r2, float r2_scale,
@@ -153,9 +153,9 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel_sync(const T* __restrict__
     __shared__ float red[4];
     const int c = blockIdx.x;
     const int hv = HW / V, total = N * hv;
-    float x1[CH_VECS][V], x2[TWO ? CH_VECS : 1][V];
+    float x1[NV][V], x2[TWO ? NV : 1][V];
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {                      // the channel's loads are in flight under the combine
+    for (int u = 0; u < NV; ++u) {                      // the channel's loads are in flight under the combine
         const int j = threadIdx.x + u * TPB;
         if (j < total) {
             const int n = j / hv, i = j - n * hv;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel_sync(const T* __restrict__
     float a2 = 0.f, o2 = 0.f;
     if constexpr (TWO) { a2 = p.gamma2[c] * is2; o2 = p.beta2[c] - mu2 * a2; }
 #pragma unroll
-    for (int u = 0; u < CH_VECS; ++u) {
+    for (int u = 0; u < NV; ++u) {
         const int j = threadIdx.x + u * TPB;
         if (j < total) {
             const int n = j / hv, i = j - n * hv;
@@ -215,13 +215,13 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel_sync(const T* __restrict__
         const float cnt = (float)N * (float)HW;
         float s = 0.f;
 #pragma unroll
-        for (int u = 0; u < CH_VECS; ++u)
+        for (int u = 0; u < NV; ++u)
 #pragma unroll
             for (int k = 0; k < V; ++k) s += x1[u][k];
         const float mu = block_sum(s, red) / cnt;
         float q = 0.f;
 #pragma unroll
-        for (int u = 0; u < CH_VECS; ++u)
+        for (int u = 0; u < NV; ++u)
             if (threadIdx.x + u * TPB < total) {
 #pragma unroll
                 for (int k = 0; k < V; ++k) q += (x1[u][k] - mu) * (x1[u][k] - mu);
@@ -314,12 +314,15 @@ int sync_stats_impl(const void* z1, const void* z2, float* packed, float* ws, in
                     int (*plane_stats)(const void*, float*, int, int, int, void*)) {
     if (N <= 0 || C <= 0 || HW <= 0) return PPEA_ERR_ARG;
     if (C >= 64 && HW % V == 0 && (long)N * HW <= CHANNEL_ELEMS) {
-        if (z2 != nullptr)
-            hipLaunchKernelGGL((bn_stats_channel_pk<T, true>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream,
-                               (const T*)z1, (const T*)z2, packed, N, C, HW);
-        else
-            hipLaunchKernelGGL((bn_stats_channel_pk<T, false>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream,
-                               (const T*)z1, (const T*)nullptr, packed, N, C, HW);
+#define PPEA_L(NV_)                                                                                                   \
+        if (z2 != nullptr)                                                                                            \
+            hipLaunchKernelGGL((bn_stats_channel_pk<T, true, NV_>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, \
+                               (const T*)z1, (const T*)z2, packed, N, C, HW);                                         \
+        else                                                                                                          \
+            hipLaunchKernelGGL((bn_stats_channel_pk<T, false, NV_>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, \
+                               (const T*)z1, (const T*)nullptr, packed, N, C, HW)
+        PPEA_BN_NV(bn_nv(N, HW), PPEA_L);
+#undef PPEA_L
         return launch_status();
     }
     if (ws == nullptr) return PPEA_ERR_ARG;
@@ -343,21 +346,24 @@ int sync_apply_impl(const void* z1, const void* z2, const float* gathered, int w
     if (C >= 64 && (long)N * HW <= CHANNEL_ELEMS) {
         const dim3 grid((unsigned)C), blk(TPB);
         const T *a = (const T*)z1, *b = (const T*)z2, *q1 = (const T*)r1, *q2 = (const T*)r2;
-        if (packed_next != nullptr) {
-            if (z2 != nullptr)
-                hipLaunchKernelGGL((bn_fwd_channel_sync<T, true, true>), grid, blk, 0, s, a, b, g, p, eps, momentum, mask, q1, q2,
-                                   r2_scale, (T*)y, packed_next, act, N, C, HW);
-            else
-                hipLaunchKernelGGL((bn_fwd_channel_sync<T, false, true>), grid, blk, 0, s, a, b, g, p, eps, momentum, mask, q1, q2,
-                                   r2_scale, (T*)y, packed_next, act, N, C, HW);
-        } else {
-            if (z2 != nullptr)
-                hipLaunchKernelGGL((bn_fwd_channel_sync<T, true, false>), grid, blk, 0, s, a, b, g, p, eps, momentum, mask, q1, q2,
-                                   r2_scale, (T*)y, packed_next, act, N, C, HW);
-            else
-                hipLaunchKernelGGL((bn_fwd_channel_sync<T, false, false>), grid, blk, 0, s, a, b, g, p, eps, momentum, mask, q1, q2,
-                                   r2_scale, (T*)y, packed_next, act, N, C, HW);
+#define PPEA_L(NV_)                                                                                                   \
+        if (packed_next != nullptr) {                                                                                 \
+            if (z2 != nullptr)                                                                                        \
+                hipLaunchKernelGGL((bn_fwd_channel_sync<T, true, true, NV_>), grid, blk, 0, s, a, b, g, p, eps, momentum, mask, q1, q2, \
+                                   r2_scale, (T*)y, packed_next, act, N, C, HW);                                      \
+            else                                                                                                      \
+                hipLaunchKernelGGL((bn_fwd_channel_sync<T, false, true, NV_>), grid, blk, 0, s, a, b, g, p, eps, momentum, mask, q1, q2, \
+                                   r2_scale, (T*)y, packed_next, act, N, C, HW);                                      \
+        } else {                                                                                                      \
+            if (z2 != nullptr)                                                                                        \
+                hipLaunchKernelGGL((bn_fwd_channel_sync<T, true, false, NV_>), grid, blk, 0, s, a, b, g, p, eps, momentum, mask, q1, q2, \
+                                   r2_scale, (T*)y, packed_next, act, N, C, HW);                                      \
+            else                                                                                                      \
+                hipLaunchKernelGGL((bn_fwd_channel_sync<T, false, false, NV_>), grid, blk, 0, s, a, b, g, p, eps, momentum, mask, q1, q2, \
+                                   r2_scale, (T*)y, packed_next, act, N, C, HW);                                      \
         }
+        PPEA_BN_NV(bn_nv(N, HW), PPEA_L);
+#undef PPEA_L
         return launch_status();
     }
     if (packed_next != nullptr) return PPEA_ERR_UNSUPPORTED;      // statistics of the output: channel-owning workgroups only

@@ -294,7 +294,7 @@ def second_use(y):
     return getattr(y, "_second_use", y)
 
 
-def fused_bn_act_next(z, bnA, bnB, mask=None, r1=None, r2=None, r2_scale=1.0):
+def fused_bn_act_next(z, bnA, bnB, mask=None, r1=None, r2=None, r2_scale=1.0, sums=None):
     """A block's last BatchNorm (+ DropPath + residual + adapter) and the NEXT block's first BatchNorm in one launch
     per direction: -> (y, y2) = (mask * BN_A(z) + r1 + r2_scale * r2, BN_B(y)), or None when the shape / mode is not
     served by the one-launch channel kernels (the caller then runs the two BatchNorms separately).  Same numbers, running
@@ -304,7 +304,7 @@ def fused_bn_act_next(z, bnA, bnB, mask=None, r1=None, r2=None, r2_scale=1.0):
         # several ranks: stats(z) -> gather -> [apply A + local statistics of y] -> gather -> apply B: the second
         # BatchNorm needs no statistics launch, and its backward adds the residual use's gradient of y in its apply launch
         group = getattr(bnA, "group", None)
-        y, stA, tab = ops.sync_bn_act(z, bnA, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, group=group, emit=True)
+        y, stA, tab = ops.sync_bn_act(z, bnA, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, group=group, emit=True, sums=sums)
         _book_sync([(z, bnA)], stA, z)
         want_skip = bool(torch.is_grad_enabled() and y.requires_grad)
         outs = ops.sync_bn_act(y, bnB, group=group, table=tab, skip=want_skip, dup=bool(want_skip and BN_DUP))

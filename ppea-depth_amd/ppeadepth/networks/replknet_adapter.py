@@ -164,8 +164,11 @@ class PointwiseConv(nn.Conv2d):
         """-> (conv(x), sums or None): on the MFMA path, for activations whose BatchNorm takes separate statistics and
         apply launches (N * HW > 16 384: stages 0 / 1; `always`: any size), the GEMM's epilogue also returns the per-channel
         partial sums that BatchNorm needs (`fused_bn_act(..., sums=sums)`)."""
+        from ..batchnorm import _collectives_on
+        # (several ranks: BatchNorm statistics are a launch of their own at every size -- the all-gather sits between them
+        # and the apply launch -- so the epilogue sums replace a pass over the activation at stages 2 / 3 as well)
         if (PW_MFMA and BN_SUMS and x.is_cuda and x.dtype == torch.bfloat16 and not self.weight.requires_grad
-                and (always or x.shape[0] * x.shape[2] * x.shape[3] > 16384)):
+                and (always or x.shape[0] * x.shape[2] * x.shape[3] > 16384 or _collectives_on())):
             r = ops.pwconv_frozen(x, self.weight, want_sums=True)
             if r is not None:
                 return r
@@ -419,7 +422,7 @@ class ConvFFN(nn.Module):
                 join()
             mask = _drop_mask(self.drop_path, x)
             if next_bn is not None:
-                pair = fused_bn_act_next(z, self.pw2.bn, next_bn, mask=mask, r1=x, r2=adpt, r2_scale=self.gamma)
+                pair = fused_bn_act_next(z, self.pw2.bn, next_bn, mask=mask, r1=x, r2=adpt, r2_scale=self.gamma, sums=s2)
                 if pair is not None:
                     return pair
             y = fused_bn_act(z, self.pw2.bn, mask=mask, r1=x, r2=adpt, r2_scale=self.gamma, sums=s2)
@@ -500,7 +503,7 @@ class RepLKBlock(nn.Module):
                 join()
             mask = _drop_mask(self.drop_path, x)
             if next_bn is not None:
-                pair = fused_bn_act_next(z, self.pw2.bn, next_bn, mask=mask, r1=x, r2=adpt, r2_scale=self.gamma)
+                pair = fused_bn_act_next(z, self.pw2.bn, next_bn, mask=mask, r1=x, r2=adpt, r2_scale=self.gamma, sums=s2)
                 if pair is not None:
                     return pair
             y = fused_bn_act(z, self.pw2.bn, mask=mask, r1=x, r2=adpt, r2_scale=self.gamma, sums=s2)
