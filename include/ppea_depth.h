@@ -144,6 +144,13 @@ int ppea_pwgrad_bf16(const void* P, const void* Q, float* out, void* workspace, 
  * [Ch][N][3][3]; out_b (may be NULL) = row sums of rows [b_row0, b_row0 + b_rows). */
 int ppea_pwgrad_ex_bf16(const void* P, const void* Q, void* workspace, int B, int M, int N, int HW, void* out_w,
                         int out_w_bf16, int taps, void* out_b, int out_b_bf16, int b_row0, int b_rows, void* stream);
+/* Two such problems over the same [B][.][HW] pixels (an adapter's D_fc2 and D_fc1 weight gradients, replknet_adapter.py:20-109)
+ * in ONE GEMM launch and ONE reduce launch; every argument that differs is an array of two.  HW % 32 == 0, else
+ * PPEA_ERR_UNSUPPORTED / a workspace size of -1: call ppea_pwgrad_ex_bf16 twice. */
+long ppea_pwgrad_pair_workspace_bytes(int B, const int* M, const int* N, int HW);
+int ppea_pwgrad_ex_pair_bf16(const void* const* P, const void* const* Q, void* workspace, int B, const int* M, const int* N,
+                             int HW, void* const* out_w, const int* out_w_bf16, const int* taps, void* const* out_b,
+                             const int* out_b_bf16, const int* b_row0, const int* b_rows, void* stream);
 int ppea_tapsum_fwd_bf16(const void* T, const void* bias, int bias_bf16, void* pre, void* h, int B, int Ch, int H,
                          int W, void* stream);
 int ppea_tapsum_bwd_bf16(const void* g, void* dT, int B, int Ch, int H, int W, void* stream);

@@ -142,9 +142,9 @@ constexpr int NSTAGE2 = 3;
 template <int BK> __device__ __forceinline__ int g_swz16(int row) { return BK == 64 ? ((row >> 1) & 7) : (2 * ((row >> 2) & 1)); }
 
 template <int BK>
-__global__ __launch_bounds__(256) void pwgrad2_kernel(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q,
-                                                      float* __restrict__ ws, int M, int N, int HW, int spi,
-                                                      int total_steps, int sps, int want_rowsum) {
+__device__ __forceinline__ void pwgrad2_body(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q,
+                                             float* __restrict__ ws, int M, int N, int HW, int spi, int total_steps,
+                                             int sps, bool rowsum_tile, int split, int m0, int n0) {
     constexpr int RB = BK * 2;                          // bytes per tile row
     constexpr int TILE = TM * RB, STAGE = 2 * TILE;
     constexpr int INS = TILE / 1024 / 4;                // LDS-DMA instructions per wave, operand and stage
@@ -153,7 +153,6 @@ __global__ __launch_bounds__(256) void pwgrad2_kernel(const uint16_t* __restrict
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int split = blockIdx.x, m0 = blockIdx.y * TM, n0 = blockIdx.z * TN;
     const int s_begin = split * sps, s_end = min(s_begin + sps, total_steps);
 
     // per-lane source pointers inside image 0 (advanced per step by a wave-uniform offset)
@@ -200,7 +199,7 @@ __global__ __launch_bounds__(256) void pwgrad2_kernel(const uint16_t* __restrict
             a_off[i][h] = ra * RB + 16 * ((4 * h + g) ^ g_swz16<BK>(ra));
             b_off[i][h] = TILE + rb * RB + 16 * ((4 * h + g) ^ g_swz16<BK>(rb));
         }
-    const bool do_rs = want_rowsum && blockIdx.z == 0 && wn == 0;
+    const bool do_rs = rowsum_tile && wn == 0;
 
     const int nsteps = s_end - s_begin;
     if (nsteps > 0) issue(s_begin, 0);
@@ -269,6 +268,29 @@ __global__ __launch_bounds__(256) void pwgrad2_kernel(const uint16_t* __restrict
     }
 }
 
+template <int BK>
+__global__ __launch_bounds__(256) void pwgrad2_kernel(const uint16_t* __restrict__ P, const uint16_t* __restrict__ Q,
+                                                      float* __restrict__ ws, int M, int N, int HW, int spi,
+                                                      int total_steps, int sps, int want_rowsum) {
+    pwgrad2_body<BK>(P, Q, ws, M, N, HW, spi, total_steps, sps, want_rowsum && blockIdx.z == 0, blockIdx.x, blockIdx.y * TM,
+                     blockIdx.z * TN);
+}
+
+// Two weight-gradient GEMMs over the same pixels in ONE launch (an adapter's D_fc2 and D_fc1 gradients: 0.75 GFLOP each, a
+// launch's fixed latency several times the arithmetic): blockIdx.y walks the tiles of problem 0, then those of problem 1.
+struct PwgProb { const uint16_t *P, *Q; float* ws; int M, N, want_rowsum, mt; };     // mt: tiles along M
+template <int BK>
+__global__ __launch_bounds__(256) void pwgrad2_pair_kernel(PwgProb a, PwgProb b, int tiles_a, int HW, int spi, int total_steps,
+                                                           int sps) {
+    int t = blockIdx.y;
+    const bool second = t >= tiles_a;
+    if (second) t -= tiles_a;
+    const PwgProb& pr = second ? b : a;
+    const int mi = t % pr.mt, ni = t / pr.mt;
+    pwgrad2_body<BK>(pr.P, pr.Q, pr.ws, pr.M, pr.N, HW, spi, total_steps, sps, pr.want_rowsum && ni == 0, blockIdx.x, mi * TM,
+                     ni * TN);
+}
+
 // out[i] = sum_s ws[s * pitch + i], i < len.  Block = 32 columns x 8 split groups, combined through LDS.
 __global__ __launch_bounds__(256) void pwgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                             long len, long pitch, int S) {
@@ -291,14 +313,18 @@ __global__ __launch_bounds__(256) void pwgrad_reduce_kernel(const float* __restr
 // Same reduction, written straight into the parameter gradients: weights as fp32 or bf16, either [M][N] or,
 // for the tap-major 3x3 form (taps = 9, M = 9 * Ch rows t * Ch + m), in nn.Conv2d layout [Ch][N][3][3];
 // bias = row sums of rows [b_row0, b_row0 + b_rows).
-__global__ __launch_bounds__(256) void pwgrad_reduce_ex_kernel(const float* __restrict__ ws, long pitch, int S, int M,
-                                                               int N, int taps, void* __restrict__ out_w,
-                                                               int w_bf16, void* __restrict__ out_b, int b_bf16,
-                                                               int b_row0, int b_rows) {
+struct PwgOut { const float* ws; long pitch; int M, N, taps; void* out_w; int w_bf16; void* out_b; int b_bf16, b_row0, b_rows; };
+
+__device__ __forceinline__ void pwgrad_reduce_ex_body(const PwgOut& o_, int S, long block) {
+    const float* __restrict__ ws = o_.ws;
+    const long pitch = o_.pitch;
+    const int M = o_.M, N = o_.N, taps = o_.taps, w_bf16 = o_.w_bf16, b_bf16 = o_.b_bf16, b_row0 = o_.b_row0, b_rows = o_.b_rows;
+    void* out_w = o_.out_w;
+    void* out_b = o_.out_b;
     __shared__ float part[8][33];
     const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
     const long len = (long)M * N + M;
-    const long i = (long)blockIdx.x * 32 + x;
+    const long i = block * 32 + x;
     float v = 0.f;
     if (i < len)
         for (int s = y; s < S; s += 8) v += ws[(long)s * pitch + i];
@@ -324,6 +350,17 @@ __global__ __launch_bounds__(256) void pwgrad_reduce_ex_kernel(const float* __re
             else reinterpret_cast<float*>(out_b)[r] = t;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void pwgrad_reduce_ex_kernel(const float* __restrict__ ws, long pitch, int S, int M,
+                                                               int N, int taps, void* __restrict__ out_w,
+                                                               int w_bf16, void* __restrict__ out_b, int b_bf16,
+                                                               int b_row0, int b_rows) {
+    pwgrad_reduce_ex_body(PwgOut{ws, pitch, M, N, taps, out_w, w_bf16, out_b, b_bf16, b_row0, b_rows}, S, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void pwgrad_reduce_ex2_kernel(PwgOut a, PwgOut b, int S, int blocks_a) {
+    if ((int)blockIdx.x < blocks_a) pwgrad_reduce_ex_body(a, S, blockIdx.x);
+    else pwgrad_reduce_ex_body(b, S, (long)blockIdx.x - blocks_a);
 }
 
 // v2 (LDS-DMA ring) serves planes whose size is a multiple of its 32-pixel step; PPEA_PWGRAD_V2=0: v1 everywhere
@@ -408,6 +445,56 @@ int ppea_pwgrad_ex_bf16(const void* P, const void* Q, void* workspace, int B, in
     hipLaunchKernelGGL(pwgrad_reduce_ex_kernel, dim3((unsigned)((len + 31) / 32)), dim3(256), 0, st,
                        (const float*)workspace, pitch, S, M, N, taps, out_w, out_w_bf16, out_b, out_b_bf16, b_row0,
                        b_rows);
+    return launch_status();
+}
+
+
+// Two ppea_pwgrad_ex_bf16 problems over the same [B][.][HW] pixels in one GEMM launch and one reduce launch (an adapter's
+// two weight gradients).  Arrays of two: P, Q, M, N, out_w, out_w_bf16, taps, out_b, out_b_bf16, b_row0, b_rows; workspace
+// of ppea_pwgrad_pair_workspace_bytes (-1: not served).  PPEA_ERR_UNSUPPORTED (HW % 32 != 0 ...): call the single form twice.
+static void pair_plan(int B, const int* M, const int* N, int HW, int& tiles, int& spi, int& total, int& sps, int& S) {
+    tiles = ((M[0] + TM - 1) / TM) * ((N[0] + TN - 1) / TN) + ((M[1] + TM - 1) / TM) * ((N[1] + TN - 1) / TN);
+    spi = HW / 32;
+    total = B * spi;
+    int want = (288 + tiles - 1) / tiles;
+    if (want > (total + 7) / 8) want = (total + 7) / 8;
+    if (want < 1) want = 1;
+    sps = (total + want - 1) / want;
+    S = (total + sps - 1) / sps;
+}
+long ppea_pwgrad_pair_workspace_bytes(int B, const int* M, const int* N, int HW) {
+    if (B <= 0 || HW <= 0 || pwgrad_bk(HW) != 32 || M[0] <= 0 || M[1] <= 0 || N[0] <= 0 || N[1] <= 0) return -1;
+    int tiles, spi, total, sps, S;
+    pair_plan(B, M, N, HW, tiles, spi, total, sps, S);
+    return (long)S * ((long)M[0] * N[0] + M[0] + (long)M[1] * N[1] + M[1]) * 4;
+}
+int ppea_pwgrad_ex_pair_bf16(const void* const* P, const void* const* Q, void* workspace, int B, const int* M, const int* N,
+                             int HW, void* const* out_w, const int* out_w_bf16, const int* taps, void* const* out_b,
+                             const int* out_b_bf16, const int* b_row0, const int* b_rows, void* stream) {
+    if (B <= 0 || HW <= 0 || pwgrad_bk(HW) != 32) return PPEA_ERR_UNSUPPORTED;
+    for (int k = 0; k < 2; ++k) {
+        if (M[k] <= 0 || N[k] <= 0 || taps[k] < 1 || (M[k] % taps[k]) != 0) return PPEA_ERR_UNSUPPORTED;
+        if (out_w[k] == nullptr || (out_b[k] != nullptr && (b_row0[k] < 0 || b_row0[k] + b_rows[k] > M[k]))) return PPEA_ERR_ARG;
+    }
+    int tiles, spi, total, sps, S;
+    pair_plan(B, M, N, HW, tiles, spi, total, sps, S);
+    if (tiles > 65535) return PPEA_ERR_UNSUPPORTED;
+    const int mt0 = (M[0] + TM - 1) / TM, nt0 = (N[0] + TN - 1) / TN, mt1 = (M[1] + TM - 1) / TM;
+    const long pitch0 = (long)M[0] * N[0] + M[0], pitch1 = (long)M[1] * N[1] + M[1];
+    float* ws0 = (float*)workspace;
+    float* ws1 = ws0 + (long)S * pitch0;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int smem = NSTAGE2 * 2 * TM * 64;
+    const PwgProb a{(const uint16_t*)P[0], (const uint16_t*)Q[0], ws0, M[0], N[0], out_b[0] != nullptr ? 1 : 0, mt0};
+    const PwgProb b{(const uint16_t*)P[1], (const uint16_t*)Q[1], ws1, M[1], N[1], out_b[1] != nullptr ? 1 : 0, mt1};
+    hipLaunchKernelGGL(pwgrad2_pair_kernel<32>, dim3(S, tiles, 1), dim3(256), smem, st, a, b, mt0 * nt0, HW, spi, total, sps);
+    const int err = launch_status();
+    if (err != 0) return err;
+    const long len0 = out_b[0] != nullptr ? pitch0 : (long)M[0] * N[0], len1 = out_b[1] != nullptr ? pitch1 : (long)M[1] * N[1];
+    const int nb0 = (int)((len0 + 31) / 32), nb1 = (int)((len1 + 31) / 32);
+    const PwgOut oa{ws0, pitch0, M[0], N[0], taps[0], out_w[0], out_w_bf16[0], out_b[0], out_b_bf16[0], b_row0[0], b_rows[0]};
+    const PwgOut ob{ws1, pitch1, M[1], N[1], taps[1], out_w[1], out_w_bf16[1], out_b[1], out_b_bf16[1], b_row0[1], b_rows[1]};
+    hipLaunchKernelGGL(pwgrad_reduce_ex2_kernel, dim3((unsigned)(nb0 + nb1)), dim3(256), 0, st, oa, ob, S, nb0);
     return launch_status();
 }
 

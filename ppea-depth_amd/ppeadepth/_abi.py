@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libppea_depth.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -38,6 +38,8 @@ SIGNATURES = {
     "ppea_pwgrad_workspace_bytes": [_i, _i, _i, _i],
     "ppea_pwgrad_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ppea_pwgrad_ex_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "ppea_pwgrad_pair_workspace_bytes": [_i, _vp, _vp, _i],
+    "ppea_pwgrad_ex_pair_bf16": [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ppea_nhwc_bn_slabs": [_i, _i],
     "ppea_nhwc_bn_stats_f32": [_vp, _vp, _i, _i, _i, _vp],
     "ppea_nhwc_bn_stats_bf16": [_vp, _vp, _i, _i, _i, _vp],

@@ -1326,6 +1326,39 @@ def pwgrad_into(p, q, w_shape, w_dtype, taps=1, b_rows=None, b_dtype=None):
     return dw, db
 
 
+PWGRAD_PAIR = __import__("os").environ.get("PPEA_PWGRAD_PAIR", "1") == "1"
+
+
+def pwgrad_into_pair(a, b):
+    """Two pwgrad_into problems over the same pixels -- a, b = (p, q, w_shape, w_dtype, taps, b_rows, b_dtype) -- in ONE GEMM
+    launch and ONE reduce launch (an adapter's D_fc2 and D_fc1 weight gradients); falls back to two calls where the pair
+    form is not served.  -> ((dw_a, db_a), (dw_b, db_b))."""
+    (pa, qa), (pb, qb) = a[:2], b[:2]
+    B, _, H, W = pa.shape
+    if PWGRAD_PAIR and pb.shape[0] == B and pb.shape[2:] == pa.shape[2:]:
+        Ms = (_ct.c_int * 2)(pa.shape[1], pb.shape[1])
+        Ns = (_ct.c_int * 2)(qa.shape[1], qb.shape[1])
+        nbytes = _abi.lib.ppea_pwgrad_pair_workspace_bytes(B, Ms, Ns, H * W)
+        if nbytes > 0:
+            dev = pa.device
+            ws = torch.empty(nbytes // 4, device=dev, dtype=_F32)
+            outs = []
+            for (_p, _q, w_shape, w_dtype, taps, b_rows, b_dtype) in (a, b):
+                outs.append((torch.empty(w_shape, device=dev, dtype=w_dtype),
+                             torch.empty(b_rows[1], device=dev, dtype=b_dtype) if b_rows is not None else None))
+            i2 = _ct.c_int * 2
+
+            def vp2(u, v, dt=None):                       # array of two device pointers (None -> NULL)
+                return (_ct.c_void_p * 2)(*(None if t_ is None else ptr(t_, dt).value for t_ in (u, v)))
+            rows = [x[5] if x[5] is not None else (0, 0) for x in (a, b)]
+            call("ppea_pwgrad_ex_pair_bf16", vp2(pa, pb, _BF16), vp2(qa, qb, _BF16), ptr(ws), B,
+                 Ms, Ns, H * W, vp2(outs[0][0], outs[1][0]), i2(int(a[3] == _BF16), int(b[3] == _BF16)),
+                 i2(a[4], b[4]), vp2(outs[0][1], outs[1][1]), i2(int(a[6] == _BF16), int(b[6] == _BF16)),
+                 i2(rows[0][0], rows[1][0]), i2(rows[0][1], rows[1][1]), stream_ptr())
+            return outs[0], outs[1]
+    return pwgrad_into(*a), pwgrad_into(*b)
+
+
 def tapsum_fwd(T, bias, Ch):
     B, _, H, W = T.shape
     pre = torch.empty(B, Ch, H, W, device=T.device, dtype=_BF16)
@@ -1390,8 +1423,8 @@ class _MlpAdapterFn(torch.autograd.Function):
         C, Ch = w2m.shape
         dy = dy.contiguous()
         g = pwconv_ex(w2m, dy, None, EPI_DGELU, pre, transposed=True)          # W2^T dy: At = W2 [C][Ch]
-        dw2, db2 = pwgrad_into(dy, h, ctx.shapes[1], t[2], 1, (0, C), t[3])
-        dw1, db1 = pwgrad_into(g, x, ctx.shapes[0], t[0], 1, (0, Ch), t[1])
+        (dw2, db2), (dw1, db1) = pwgrad_into_pair((dy, h, ctx.shapes[1], t[2], 1, (0, C), t[3]),
+                                                  (g, x, ctx.shapes[0], t[0], 1, (0, Ch), t[1]))
         dx = pwconv_ex(w1m, g, transposed=True) if ctx.needs_input_grad[0] else None
         return dx, dw1, db1, dw2, db2
 
@@ -1421,9 +1454,9 @@ class _ConvAdapterFn(torch.autograd.Function):
         C, Ch = w2m.shape
         dy = dy.contiguous()
         g = pwconv_ex(w2m, dy, None, EPI_DGELU, pre, transposed=True)
-        dw2, db2 = pwgrad_into(dy, h, ctx.shapes[1], t[2], 1, (0, C), t[3])
         dT = tapsum_bwd(g)
-        dw1, db1 = pwgrad_into(dT, x, ctx.shapes[0], t[0], 9, (4 * Ch, Ch), t[1])   # centre-tap rows == g
+        (dw2, db2), (dw1, db1) = pwgrad_into_pair((dy, h, ctx.shapes[1], t[2], 1, (0, C), t[3]),
+                                                  (dT, x, ctx.shapes[0], t[0], 9, (4 * Ch, Ch), t[1]))   # centre-tap rows == g
         dx = pwconv_ex(a1, dT, transposed=True) if ctx.needs_input_grad[0] else None  # At = a1 [9*Ch][C]
         return dx, dw1, db1, dw2, db2
 

@@ -461,6 +461,29 @@ def test_pwconv_mfma(device, B, M, K, H, W):
     assert (xd.grad.float().cpu() - gref).abs().max() <= gref.abs().max() * 2 ** -7
 
 
+@pytest.mark.parametrize("B,C,Ch,H,W,taps", [(12, 512, 128, 12, 40, 1), (3, 128, 32, 48, 160, 1), (2, 256, 64, 24, 80, 9),
+                                              (2, 200, 160, 8, 12, 1), (2, 64, 32, 6, 20, 1)])
+def test_pwgrad_pair_equals_two_launches(device, B, C, Ch, H, W, taps):
+    """An adapter's two weight gradients (D_fc2: dy x h, D_fc1: g x x, the latter tap-major for the 3x3 form) in ONE GEMM
+    launch + ONE reduce launch against the two-launch form: same sums to fp32 summation order (the split count differs),
+    bias gradients included; shapes whose planes are not a multiple of 32 pixels fall back to the two launches."""
+    from ppeadepth import ops
+    g = _g(B + C + Ch)
+    dy = torch.randn(B, C, H, W, generator=g).bfloat16().to(device)
+    h = torch.randn(B, Ch, H, W, generator=g).bfloat16().to(device)
+    gg = torch.randn(B, taps * Ch, H, W, generator=g).bfloat16().to(device)
+    x = torch.randn(B, C, H, W, generator=g).bfloat16().to(device)
+    w1_shape = (Ch, C, 3, 3) if taps == 9 else (Ch, C)
+    a = (dy, h, (C, Ch), torch.float32, 1, (0, C), torch.float32)
+    b = (gg, x, w1_shape, torch.bfloat16, taps, ((4 * Ch, Ch) if taps == 9 else (0, Ch)), torch.bfloat16)
+    (dw2, db2), (dw1, db1) = ops.pwgrad_into_pair(a, b)
+    r2, r1 = ops.pwgrad_into(*a), ops.pwgrad_into(*b)
+    assert rel_err(dw2, r2[0]) < 1e-5 and rel_err(db2, r2[1]) < 1e-5
+    assert rel_err(dw1.float(), r1[0].float()) < 2 ** -7 and rel_err(db1.float(), r1[1].float()) < 2 ** -7
+    ref = torch.einsum("bmp,bnp->mn", dy.float().flatten(2), h.float().flatten(2))
+    assert rel_err(dw2, ref) < 1e-4
+
+
 @pytest.mark.parametrize("epi", ["none", "dgelu"])
 @pytest.mark.parametrize("B,M,K,H,W", [(12, 128, 512, 12, 40), (3, 512, 128, 12, 40), (2, 160, 128, 24, 80), (2, 72, 96, 6, 20),
                                        (1, 1024, 256, 5, 8), (2, 128, 1152, 12, 40)])
