@@ -652,6 +652,33 @@ def test_adam_flat_matches_torch_adam(device):
     assert torch.equal(W16, P[:n_lo].bfloat16())
 
 
+def test_adam_flat_scaled_divides_rank_summed_gradients(device):
+    """Several ranks: the exchange leaves the SUM of the gradients over the ranks in the flat buffer and the Adam kernel
+    multiplies by 1 / world as it reads them -- bit-identical to a separate scaling pass followed by the plain kernel."""
+    from ppeadepth._abi import call, ptr, stream_ptr
+    g = _g(6)
+    n, n_lo, world = 5003, 1024, 8
+    p0 = torch.randn(n, generator=g).to(device)
+    res = []
+    for fused in (False, True):
+        P, M, V = p0.clone(), torch.zeros(n, device=device), torch.zeros(n, device=device)
+        W16 = torch.empty(n_lo, device=device, dtype=torch.bfloat16)
+        state = torch.tensor([0.0, 1e-3], device=device)
+        gg = _g(7)
+        for step in range(3):
+            gsum = (torch.randn(n, generator=gg) * 3.0).to(device)
+            state[0] += 1
+            if fused:
+                call("ppea_adam_flat_scaled_f32", ptr(P), ptr(gsum), ptr(M), ptr(V), ptr(W16), n, n_lo, ptr(state), 0.9, 0.999,
+                     1e-8, 1.0 / world, stream_ptr())
+            else:
+                call("ppea_adam_flat_f32", ptr(P), ptr(gsum * (1.0 / world)), ptr(M), ptr(V), ptr(W16), n, n_lo, ptr(state), 0.9,
+                     0.999, 1e-8, stream_ptr())
+        res.append((P, M, V, W16))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 5, 7, 9), (3, 16, 24, 80), (1, 4, 192, 640)])
 def test_bias_elu(device, dtype, shape):
