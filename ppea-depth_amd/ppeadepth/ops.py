@@ -622,7 +622,7 @@ def _other_stream_grad(g):
     stream.  The autograd engine makes the consumer stream wait for the producer, but for a gradient that is not accumulated
     with another one it does not record the consumer on the tensor -- the block would go back to the producer stream's pool
     as soon as this backward returns and could be rewritten by that stream's next allocation while the kernel launched here
-    has not run yet (seen as wrong encoder gradients in replayed hipGraphs, where such a reuse is baked in)."""
+    has not run yet.  (A precaution: the alias is only handed to consumers on the SAME stream, see rka.ConvFFN.forward.)"""
     if g is not None and g.is_cuda:
         g.record_stream(torch.cuda.current_stream())
 
