@@ -207,6 +207,15 @@ int ppea_bn_fwd_channel_f32(const void* z1, const void* z2, const float* const* 
 int ppea_bn_fwd_channel_bf16(const void* z1, const void* z2, const float* const* prm, float* const* out, float eps,
                              float momentum, const float* mask, const void* r1, const void* r2, float r2_scale, void* y,
                              int act, int N, int C, int HW, void* stream);
+/* The same forward for ONE BatchNorm whose statistics come from the producing GEMM's epilogue (partial [C][P][2] from
+ * ppea_pwconv_stats_bf16): no reduction over the activation, no workgroup barrier.  prm = {gamma, beta}; out =
+ * {running_mean, running_var (NULL: no update), mean, invstd}.  Backward: ppea_bn_bwd_channel_*. */
+int ppea_bn_fwd_channel_sums_f32(const void* z, const float* partial, int P, const float* const* prm, float* const* out,
+                                 float eps, float momentum, const float* mask, const void* r1, const void* r2, float r2_scale,
+                                 void* y, int act, int N, int C, int HW, void* stream);
+int ppea_bn_fwd_channel_sums_bf16(const void* z, const float* partial, int P, const float* const* prm, float* const* out,
+                                  float eps, float momentum, const float* mask, const void* r1, const void* r2, float r2_scale,
+                                  void* y, int act, int N, int C, int HW, void* stream);
 /* acc (or NULL): a gradient that reaches z1 through another consumer (the block's residual connection, rka.py:289, 326);
  * dz1 = BN-backward(dy) + acc in the same launch instead of a separate element-wise add. */
 int ppea_bn_bwd_channel_f32(const void* dy, const void* z1, const void* z2, const float* const* stats, const float* mask,

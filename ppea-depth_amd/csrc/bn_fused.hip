@@ -573,6 +573,72 @@ __global__ __launch_bounds__(TPB) void bn_fwd_channel(const T* __restrict__ z1, 
     }
 }
 
+// The same forward with the statistics taken from partial sums the PRODUCING GEMM left in its epilogue
+// (ppea_pwconv_stats_bf16: partial [C][P][2] = (sum, sum of squares) of disjoint pixel sets of the stored values): no
+// reduction over the activation and no workgroup barrier -- every wave finalises the channel itself (fp64, the arithmetic and
+// order of bn_finalize_sums) while its loads of the channel are in flight, then applies.  The FFN's BatchNorm + GELU over the
+// 4C-wide hidden tensor (rka.py:264-289) is the user: 47 MB per launch at stage 2.
+template <typename T, int NV>
+__global__ __launch_bounds__(TPB) void bn_fwd_channel_sums(const T* __restrict__ z1, const float* __restrict__ partial, int P,
+                                                           FwdPrm p, float eps, float momentum,
+                                                           const float* __restrict__ mask, const T* __restrict__ r1,
+                                                           const T* __restrict__ r2, float r2_scale, T* __restrict__ y,
+                                                           int act, int N, int C, int HW) {
+    const int c = blockIdx.x, lane = threadIdx.x & 63;
+    const int hv = HW / V, total = N * hv;
+    const double cnt = (double)N * (double)HW;
+    float x1[NV][V];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j < total) {
+            const int n = j / hv, i = j - n * hv;
+            ld8<T>(z1 + ((long)n * C + c) * HW + i * V, x1[u]);
+        }
+    }
+    const float2* sp = reinterpret_cast<const float2*>(partial) + (long)c * P;
+    double ds = 0.0, dq = 0.0;
+#pragma unroll 8
+    for (int i = lane; i < P; i += 64) {
+        const float2 v = sp[i];
+        ds += (double)v.x; dq += (double)v.y;
+    }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) { ds += __shfl_xor(ds, k, WAVE); dq += __shfl_xor(dq, k, WAVE); }
+    const double mean = ds / cnt;
+    double var = dq / cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float mu1 = (float)mean, is1 = rsqrtf((float)var + eps);
+    if (threadIdx.x == 0) {
+        p.mean1[c] = mu1; p.invstd1[c] = is1;
+        if (p.rm1 != nullptr) {
+            const float unbiased = (float)(var * cnt / fmax(cnt - 1.0, 1.0));
+            p.rm1[c] = (1.f - momentum) * p.rm1[c] + momentum * mu1;
+            p.rv1[c] = (1.f - momentum) * p.rv1[c] + momentum * unbiased;
+        }
+    }
+    const float a1 = p.gamma1[c] * is1, o1 = p.beta1[c] - mu1 * a1;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int j = threadIdx.x + u * TPB;
+        if (j >= total) break;
+        const int n = j / hv, i = j - n * hv;
+        const long off = ((long)n * C + c) * HW + i * V;
+        const float m = (mask != nullptr) ? mask[n] : 1.f;
+        float e1[V], e2[V], o[V];
+        if (r1 != nullptr) ld8<T>(r1 + off, e1);
+        if (r2 != nullptr) ld8<T>(r2 + off, e2);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float v = act_fwd<T>(a1 * x1[u][k] + o1, act) * m;
+            if (r1 != nullptr) v += e1[k];
+            if (r2 != nullptr) v += r2_scale * e2[k];
+            o[k] = v;
+        }
+        st8<T>(y + off, o);
+    }
+}
+
 template <typename T, bool TWO, int NV>
 __global__ __launch_bounds__(TPB) void bn_bwd_channel(const T* __restrict__ dy, const T* __restrict__ dyb, const T* __restrict__ z1,
                                                       const T* __restrict__ z2, Branch b1, Branch b2,
@@ -1056,6 +1122,21 @@ int fwd_channel_impl(const void* z1, const void* z2, const float* const* prm, fl
     return launch_status();
 }
 template <typename T>
+int fwd_channel_sums_impl(const void* z1, const float* partial, int P, const float* const* prm, float* const* outp, float eps,
+                          float momentum, const float* mask, const void* r1, const void* r2, float r2_scale, void* y, int act,
+                          int N, int C, int HW, void* stream) {
+    if (N <= 0 || C < 64 || HW <= 0 || (HW % V) != 0 || (long)N * HW > CHANNEL_ELEMS || act < 0 || act > 2)
+        return PPEA_ERR_UNSUPPORTED;
+    if (partial == nullptr || P <= 0) return PPEA_ERR_ARG;
+    FwdPrm p{prm[0], prm[1], nullptr, nullptr, outp[0], outp[1], nullptr, nullptr, outp[2], outp[3], nullptr, nullptr};
+#define PPEA_L(NV_)                                                                                                   \
+    hipLaunchKernelGGL((bn_fwd_channel_sums<T, NV_>), dim3((unsigned)C), dim3(TPB), 0, (hipStream_t)stream, (const T*)z1, partial, \
+                       P, p, eps, momentum, mask, (const T*)r1, (const T*)r2, r2_scale, (T*)y, act, N, C, HW)
+    PPEA_BN_NV(bn_nv(N, HW), PPEA_L);
+#undef PPEA_L
+    return launch_status();
+}
+template <typename T>
 int bwd_channel_impl(const void* dy, const void* dyb, const void* z1, const void* z2, const float* const* st, const float* mask,
                      float inv_count, const void* acc, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW,
                      void* stream) {
@@ -1155,6 +1236,18 @@ int ppea_bn_fwd_channel_bf16(const void* z1, const void* z2, const float* const*
                              float momentum, const float* mask, const void* r1, const void* r2, float r2_scale, void* y,
                              int act, int N, int C, int HW, void* stream) {
     return fwd_channel_impl<uint16_t>(z1, z2, prm, out, eps, momentum, mask, r1, r2, r2_scale, y, act, N, C, HW, stream);
+}
+// One BatchNorm, statistics from the producing GEMM's epilogue sums (partial [C][P][2], ppea_pwconv_stats_bf16):
+// prm = {gamma, beta}; out = {running_mean, running_var (NULL: no update), mean, invstd (written)}.
+int ppea_bn_fwd_channel_sums_f32(const void* z, const float* partial, int P, const float* const* prm, float* const* out,
+                                 float eps, float momentum, const float* mask, const void* r1, const void* r2, float r2_scale,
+                                 void* y, int act, int N, int C, int HW, void* stream) {
+    return fwd_channel_sums_impl<float>(z, partial, P, prm, out, eps, momentum, mask, r1, r2, r2_scale, y, act, N, C, HW, stream);
+}
+int ppea_bn_fwd_channel_sums_bf16(const void* z, const float* partial, int P, const float* const* prm, float* const* out,
+                                  float eps, float momentum, const float* mask, const void* r1, const void* r2, float r2_scale,
+                                  void* y, int act, int N, int C, int HW, void* stream) {
+    return fwd_channel_sums_impl<uint16_t>(z, partial, P, prm, out, eps, momentum, mask, r1, r2, r2_scale, y, act, N, C, HW, stream);
 }
 int ppea_bn_bwd_channel_f32(const void* dy, const void* z1, const void* z2, const float* const* stats, const float* mask,
                             float inv_count, const void* acc, void* dz1, void* dz2, float* sums, int act, int N, int C, int HW,

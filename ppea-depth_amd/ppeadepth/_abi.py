@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libppea_depth.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -112,6 +112,8 @@ SIGNATURES = {
     "ppea_loss_select_f32": [_vp] * 9 + [_i] * 5 + [_vp],
     "ppea_bn_fwd_channel_f32": [_vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp],
     "ppea_bn_fwd_channel_bf16": [_vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp],
+    "ppea_bn_fwd_channel_sums_f32": [_vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp],
+    "ppea_bn_fwd_channel_sums_bf16": [_vp, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp],
     "ppea_bn_bwd_channel_f32": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_bn_bwd_channel_bf16": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_bn_fwd_channel_next_f32": [_vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],

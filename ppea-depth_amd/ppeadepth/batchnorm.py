@@ -247,7 +247,8 @@ def fused_bn_act(z1, bn1, z2=None, bn2=None, act=0, mask=None, r1=None, r2=None,
                 y, st, z1_skip = ops.bn_act_channel(z1, bn1, z2, bn2, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act,
                                                     skip=True)
         else:
-            y, st = ops.bn_act_channel(z1, bn1, z2, bn2, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act)
+            y, st = ops.bn_act_channel(z1, bn1, z2, bn2, mask=mask, r1=r1, r2=r2, r2_scale=r2_scale, act=act,
+                                       sums=sums if (z2 is None and torch.is_tensor(sums)) else None)
         cnt = float(z1.numel() // z1.shape[1])
         for k, (_, bn) in enumerate(bns):
             if _ACTIVE_DEFERRED is None:

@@ -183,6 +183,7 @@ DW_SUMS = os.environ.get("PPEA_DW_SUMS", "0") == "1"
 # the BatchNorm + ReLU between pw1 and the large kernel applied in the depthwise kernel's staging pass (one rank)
 DW_BN_FUSE = os.environ.get("PPEA_DW_BN", "1") == "1"
 BN_SUMS = os.environ.get("PPEA_BN_SUMS", "1") == "1"   # BatchNorm statistics from the 1x1 conv's epilogue (stages 0 / 1)
+BN_SUMS_FFN = os.environ.get("PPEA_BN_SUMS_FFN", "1") == "1"   # ... for the FFN's hidden BatchNorm + GELU at stages 2 / 3 too
 ADAPTER_MFMA = True    # adapters (forward + every gradient) on the NCHW MFMA kernels under bf16
 
 
@@ -376,9 +377,9 @@ class ReparamLargeKernelConv(nn.Module):
             del self.small_conv
 
 
-def _conv_sums(conv, x):
+def _conv_sums(conv, x, always=False):
     """(conv(x), partial sums for the BatchNorm that follows or None)."""
-    return conv.forward_sums(x) if isinstance(conv, PointwiseConv) else (conv(x), None)
+    return conv.forward_sums(x, always) if isinstance(conv, PointwiseConv) else (conv(x), None)
 
 
 class ConvFFN(nn.Module):
@@ -416,7 +417,8 @@ class ConvFFN(nn.Module):
                     # stream, replayed hipGraphs of the fp32 step gave wrong encoder gradients in 2 of 3 captures (eager steps
                     # and the in-line form never did; cause not found)
                     adpt = self.mlp_adapter(second_use(out))
-            z1, s1 = _conv_sums(self.pw1.conv, out)
+            # (the BatchNorm + GELU over the 4C-wide hidden tensor takes its statistics from the GEMM's epilogue at every size)
+            z1, s1 = _conv_sums(self.pw1.conv, out, BN_SUMS_FFN)
             h = fused_bn_act(z1, self.pw1.bn, act=ops.ACT_GELU, sums=s1)
             z, s2 = _conv_sums(self.pw2.conv, h)
             if join is not None:

@@ -633,7 +633,7 @@ class _BnActChannel(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z1, g1, b1, rm1, rv1, z2, g2, b2, rm2, rv2, mask, r1, r2, r2_scale, act, eps, momentum, skip=False,
-                dup=False):
+                dup=False, sums=None):
         z1_in = z1
         z1 = z1.contiguous()
         N, C = z1.shape[0], z1.shape[1]
@@ -648,9 +648,16 @@ class _BnActChannel(torch.autograd.Function):
         maskf = None if mask is None else mask.detach().reshape(-1).float().contiguous()
         st = torch.empty(4, C, device=z1.device, dtype=_F32)          # mean1 | invstd1 | mean2 | invstd2
         y = torch.empty_like(z1)
-        call(f"ppea_bn_fwd_channel_{_suffix(z1)}", ptr(z1), ptr(z2), _ptr_array((g1f, b1f, g2f, b2f)),
-             _ptr_array((rm1, rv1, rm2, rv2, st[0], st[1], st[2], st[3])), float(eps), float(momentum), ptr(maskf),
-             ptr(r1), ptr(r2), float(r2_scale), ptr(y), int(act), N, C, HW, stream_ptr())
+        if sums is not None and z2 is None:
+            # statistics from the producing GEMM's epilogue: [C][P][2] partial (sum, sum of squares) of the stored values
+            sums = sums.contiguous()
+            call(f"ppea_bn_fwd_channel_sums_{_suffix(z1)}", ptr(z1), ptr(sums, _F32), int(sums.shape[1]), _ptr_array((g1f, b1f)),
+                 _ptr_array((rm1, rv1, st[0], st[1])), float(eps), float(momentum), ptr(maskf), ptr(r1), ptr(r2),
+                 float(r2_scale), ptr(y), int(act), N, C, HW, stream_ptr())
+        else:
+            call(f"ppea_bn_fwd_channel_{_suffix(z1)}", ptr(z1), ptr(z2), _ptr_array((g1f, b1f, g2f, b2f)),
+                 _ptr_array((rm1, rv1, rm2, rv2, st[0], st[1], st[2], st[3])), float(eps), float(momentum), ptr(maskf),
+                 ptr(r1), ptr(r2), float(r2_scale), ptr(y), int(act), N, C, HW, stream_ptr())
         ctx.save_for_backward(z1, z2, st, g1f, b1f, g2f, b2f, maskf)
         ctx.act, ctx.r2_scale = int(act), float(r2_scale)
         ctx.has = (r1 is not None, r2 is not None)
@@ -706,17 +713,17 @@ class _BnActChannel(torch.autograd.Function):
         db2 = sums[0].to(ctx.pdt[2]) if (z2 is not None and ctx.needs_input_grad[7]) else None
         dr1 = dy if ctx.has[0] else None
         dr2 = (dy if ctx.r2_scale == 1.0 else dy * ctx.r2_scale) if ctx.has[1] else None
-        return (dz1, dg1, db1, None, None, dz2, dg2, db2, None, None, None, dr1, dr2, None, None, None, None, None, None)
+        return (dz1, dg1, db1, None, None, dz2, dg2, db2, None, None, None, dr1, dr2, None, None, None, None, None, None, None)
 
 
 def bn_act_channel(z1, bn1, z2=None, bn2=None, mask=None, r1=None, r2=None, r2_scale=1.0, act=ACT_NONE, skip=False,
-                   dup=False):
+                   dup=False, sums=None):
     """-> (y, stats [4,C] = mean1 | invstd1 | mean2 | invstd2 [, z1 for the residual use when `skip`] [, y again for its
     second consumer when `dup`]).  Updates the running statistics of bn1 / bn2."""
     return _BnActChannel.apply(z1, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, z2,
                                None if bn2 is None else bn2.weight, None if bn2 is None else bn2.bias,
                                None if bn2 is None else bn2.running_mean, None if bn2 is None else bn2.running_var,
-                               mask, r1, r2, r2_scale, act, bn1.eps, bn1.momentum, skip, dup)
+                               mask, r1, r2, r2_scale, act, bn1.eps, bn1.momentum, skip, dup, sums)
 
 
 class _BnActChannelNext(torch.autograd.Function):

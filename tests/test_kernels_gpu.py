@@ -461,6 +461,37 @@ def test_pwconv_mfma(device, B, M, K, H, W):
     assert (xd.grad.float().cpu() - gref).abs().max() <= gref.abs().max() * 2 ** -7
 
 
+@pytest.mark.parametrize("N,K,M,H,W,act", [(12, 512, 2048, 12, 40, 2), (3, 128, 256, 6, 20, 1), (5, 64, 128, 12, 40, 0)])
+def test_bn_channel_statistics_from_the_gemm_epilogue(device, N, K, M, H, W, act):
+    """The one-launch channel BatchNorm with its statistics taken from the producing 1x1 conv's epilogue sums
+    (`ppea_bn_fwd_channel_sums_*`: the FFN's BatchNorm + GELU at stages 2 / 3): saved / running statistics equal to the
+    in-kernel reduction's to 1e-6 / 1e-5, outputs and gradients to bf16 rounding."""
+    from ppeadepth import ops
+    from ppeadepth.batchnorm import BatchNorm2d
+    g = _g(N + K + M)
+    x = torch.randn(N, K, H, W, generator=g).bfloat16().to(device)
+    w = (torch.randn(M, K, 1, 1, generator=g) / K ** 0.5).to(device)
+    go = torch.randn(N, M, H, W, generator=g).bfloat16().to(device)
+    res = []
+    for use_sums in (False, True):
+        bn = BatchNorm2d(M).to(device)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(M, generator=_g(1)) + 0.5)
+            bn.bias.copy_(torch.randn(M, generator=_g(2)) * 0.2)
+        xl = x.clone().requires_grad_(True)
+        z, sums = ops.pwconv_frozen(xl, w, want_sums=True)
+        outs = ops.bn_act_channel(z, bn, act=act, sums=sums if use_sums else None)
+        y, st = outs[0], outs[1]
+        y.backward(go)
+        res.append((y.detach(), st.clone(), bn.running_mean.clone(), bn.running_var.clone(), xl.grad, bn.weight.grad, bn.bias.grad))
+    a, b = res
+    assert rel_err(b[1][0], a[1][0]) < 1e-5 and rel_err(b[1][1], a[1][1]) < 1e-5
+    assert rel_err(b[2], a[2]) < 1e-5 and rel_err(b[3], a[3]) < 1e-5
+    assert rel_err(b[0].float(), a[0].float()) < 2 ** -6
+    for k in (4, 5, 6):
+        assert rel_err(b[k].float(), a[k].float()) < 2e-2, k
+
+
 @pytest.mark.parametrize("B,C,Ch,H,W,taps", [(12, 512, 128, 12, 40, 1), (3, 128, 32, 48, 160, 1), (2, 256, 64, 24, 80, 9),
                                               (2, 200, 160, 8, 12, 1), (2, 64, 32, 6, 20, 1)])
 def test_pwgrad_pair_equals_two_launches(device, B, C, Ch, H, W, taps):
