@@ -424,9 +424,6 @@ int ppea_loss_select_f32(const float* reproj, const float* identity, const float
 long ppea_conv_packed_bytes(int Cout, int Cin, int R, int S, int flip);
 int ppea_conv_pack_weights(const void* w, int w_is_bf16, void* packed, int Cout, int Cin, int R, int S, int flip,
                            void* stream);
-/* Both operand images (flip = 0 and flip = 1) of one weight in one launch. */
-int ppea_conv_pack_weights_pair(const void* w, int w_is_bf16, void* packed_fwd, void* packed_flip, int Cout, int Cin, int R,
-                                int S, void* stream);
 int ppea_conv_nhwc_bf16(const void* x, const void* w_packed, const void* bias, int bias_bf16, void* y,
                         int N, int H, int W, int Cin, int Cout, int R, int S, int stride, int pad, int reflect, int dil,
                         int Ho, int Wo, int act, int out_nchw, void* stream);

@@ -542,35 +542,21 @@ int dispatch_resident(const ConvArgs& a, hipStream_t st) {
 // weights [Cout][Cin][R][S] (bf16 or fp32) -> packed bf16 [R*S][Cout][CinP]  (flip = 0)
 //                                         -> packed bf16 [R*S][Cin][CoutP] with both taps reversed (flip = 1: dgrad)
 template <typename T>
-__device__ __forceinline__ uint16_t conv_pack_elem(const T* __restrict__ w, long i, int Cout, int Cin, int RS, int flip) {
-    const int rows = flip ? Cin : Cout, cols = flip ? Cout : Cin;
-    const int colsP = (cols + 31) / 32 * 32;
-    const int c = (int)(i % colsP);
-    const int rw = (int)((i / colsP) % rows);
-    const int tap = (int)(i / ((long)colsP * rows));
-    float v = 0.f;
-    if (c < cols) {
-        const int co = flip ? c : rw, ci = flip ? rw : c;
-        const int tp = flip ? RS - 1 - tap : tap;
-        v = ld_f32<T>(w + ((long)co * Cin + ci) * RS + tp);
-    }
-    return f2bf(v);
-}
-template <typename T>
 __global__ void conv_pack_kernel(const T* __restrict__ w, uint16_t* __restrict__ out, int Cout, int Cin, int RS, int flip) {
     const int rows = flip ? Cin : Cout, cols = flip ? Cout : Cin;
-    const long total = (long)RS * rows * ((cols + 31) / 32 * 32);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
-        out[i] = conv_pack_elem<T>(w, i, Cout, Cin, RS, flip);
-}
-// both operand images of one weight in ONE launch (a trainable weight is packed on every step: forward image now, the
-// data-gradient image for the backward pass of the same step)
-template <typename T>
-__global__ void conv_pack_pair_kernel(const T* __restrict__ w, uint16_t* __restrict__ out_fwd, uint16_t* __restrict__ out_flip,
-                                      int Cout, int Cin, int RS, long total_fwd, long total_flip) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_fwd + total_flip; i += (long)gridDim.x * blockDim.x) {
-        if (i < total_fwd) out_fwd[i] = conv_pack_elem<T>(w, i, Cout, Cin, RS, 0);
-        else out_flip[i - total_fwd] = conv_pack_elem<T>(w, i - total_fwd, Cout, Cin, RS, 1);
+    const int colsP = (cols + 31) / 32 * 32;
+    const long total = (long)RS * rows * colsP;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % colsP);
+        const int rw = (int)((i / colsP) % rows);
+        const int tap = (int)(i / ((long)colsP * rows));
+        float v = 0.f;
+        if (c < cols) {
+            const int co = flip ? c : rw, ci = flip ? rw : c;
+            const int tp = flip ? RS - 1 - tap : tap;
+            v = ld_f32<T>(w + ((long)co * Cin + ci) * RS + tp);
+        }
+        out[i] = f2bf(v);
     }
 }
 
@@ -608,20 +594,6 @@ int ppea_conv_pack_weights(const void* w, int w_is_bf16, void* packed, int Cout,
     else
         hipLaunchKernelGGL(conv_pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)w,
                            (uint16_t*)packed, Cout, Cin, R * S, flip);
-    return launch_status();
-}
-
-int ppea_conv_pack_weights_pair(const void* w, int w_is_bf16, void* packed_fwd, void* packed_flip, int Cout, int Cin, int R,
-                                int S, void* stream) {
-    if (Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0) return PPEA_ERR_ARG;
-    const long t0 = packed_elems(Cout, Cin, R, S, 0), t1 = packed_elems(Cout, Cin, R, S, 1);
-    const int blocks = (int)((t0 + t1 + 255) / 256 > 8192 ? 8192 : (t0 + t1 + 255) / 256);
-    if (w_is_bf16)
-        hipLaunchKernelGGL(conv_pack_pair_kernel<uint16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)w,
-                           (uint16_t*)packed_fwd, (uint16_t*)packed_flip, Cout, Cin, R * S, t0, t1);
-    else
-        hipLaunchKernelGGL(conv_pack_pair_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)w,
-                           (uint16_t*)packed_fwd, (uint16_t*)packed_flip, Cout, Cin, R * S, t0, t1);
     return launch_status();
 }
 

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libppea_depth.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 8
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -133,7 +133,6 @@ SIGNATURES = {
     "ppea_conv_image_wgrad_bf16": [_vp, _vp, _vp, _i, _vp] + [_i] * 10 + [_vp],
     "ppea_conv_packed_bytes": [_i] * 5,
     "ppea_conv_pack_weights": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
-    "ppea_conv_pack_weights_pair": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_image_to_nhwc_bf16": [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp],
     "ppea_conv_nhwc_bf16": [_vp, _vp, _vp, _i, _vp] + [_i] * 15 + [_vp],
     "ppea_conv_wgrad_workspace_bytes": [_i] * 8,

@@ -1617,19 +1617,6 @@ def _conv_packed(w, flip):
     return buf
 
 
-def _conv_packed_pair(w):
-    """(forward image, data-gradient image) of a TRAINABLE weight in one launch: the second one is kept for the backward
-    pass of the same step instead of a second pack launch on the backward chain."""
-    Cout, Cin, R, S = w.shape
-    wd = w.detach()
-    if wd.dtype not in (_F32, _BF16) or not wd.is_contiguous():
-        wd = wd.float().contiguous()
-    fwd = torch.empty(_abi.lib.ppea_conv_packed_bytes(Cout, Cin, R, S, 0) // 2, dtype=_BF16, device=w.device)
-    flp = torch.empty(_abi.lib.ppea_conv_packed_bytes(Cout, Cin, R, S, 1) // 2, dtype=_BF16, device=w.device)
-    call("ppea_conv_pack_weights_pair", ptr(wd), int(wd.dtype == _BF16), ptr(fwd), ptr(flp), Cout, Cin, R, S, stream_ptr())
-    return fwd, flp
-
-
 def _nhwc_raw(t):
     """Pointer of a channels_last (or C == 1 / 1x1 degenerate) 4-D tensor's storage."""
     return _ct.c_void_p(t.data_ptr())
@@ -1700,9 +1687,6 @@ def conv_supported(x, w):
             and w.shape[3] <= 7)
 
 
-CONV_PACK_PAIR = __import__("os").environ.get("PPEA_CONV_PACK_PAIR", "1") == "1"
-
-
 class _ConvNhwc(torch.autograd.Function):
     """y = act(conv2d(x, w, stride, pad | reflection pad) + bias) -- forward, data gradient and weight gradient on the
     implicit-GEMM kernels; bias gradient and the activation's derivative in one pass before them."""
@@ -1713,12 +1697,7 @@ class _ConvNhwc(torch.autograd.Function):
         N, Cin, H, W = x.shape
         Cout, _, R, S = w.shape
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
-        ctx.wt = None
-        if CONV_PACK_PAIR and w.requires_grad and ctx.needs_input_grad[0]:     # trainable weight, data gradient wanted
-            wp, ctx.wt = _conv_packed_pair(w)
-        else:
-            wp = _conv_packed(w, False)
-        y = conv_nhwc_raw(x, wp, None if bias is None else bias.detach().contiguous(), Cout, R, S, stride,
+        y = conv_nhwc_raw(x, _conv_packed(w, False), None if bias is None else bias.detach().contiguous(), Cout, R, S, stride,
                           pad, reflect, 1, Ho, Wo, act, out_nchw)
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.cfg = (stride, pad, bool(reflect), act, bool(out_nchw), bias is not None,
@@ -1756,7 +1735,7 @@ class _ConvNhwc(torch.autograd.Function):
             dz = _as_nhwc(dz.to(_BF16))
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wt = ctx.wt if ctx.wt is not None else _conv_packed(w, True)     # [R*S flipped][Cin][Cout padded to 32]
+            wt = _conv_packed(w, True)                           # [R*S flipped][Cin][Cout padded to 32]
             if reflect:
                 # gradient on the reflection-padded domain, then folded back (layers.py:119-135)
                 dpad = conv_nhwc_raw(dz, wt, None, Cin, R, S, 1, R - 1, False, stride, Ho + R - 1, Wo + S - 1, 0, False)
