@@ -356,6 +356,12 @@ int ppea_grid_sample_bwd_grid_f32(const float* src, const float* grid, const flo
                                   float* d_grid, int B, int C, int Hi, int Wi, int Ho, int Wo,
                                   int padding, void* stream);
 
+/* A15: axis-angle + translation -> 4x4 transformation (layers.py:26-42 `transformation_from_parameters`, 61-100
+ * `rot_from_axisangle`): aa, tr [B][3] fp32 -> T [B][4][4]; invert != 0: R^T T(-t).  Backward: d aa, d tr from dT. */
+int ppea_pose_matrix_fwd_f32(const float* aa, const float* tr, float* T, int B, int invert, void* stream);
+int ppea_pose_matrix_bwd_f32(const float* aa, const float* tr, const float* dT, float* daa, float* dtr, int B, int invert,
+                             void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * A21+A22  compute_reprojection_loss (trainer.py:995-1007; SSIM layers.py:226-257):
  *      out[b,0,i,j] = alpha * mean_c SSIM(pred,target) + (1-alpha) * mean_c |target-pred|.

@@ -208,6 +208,83 @@ __global__ __launch_bounds__(256) void grid_sample_bwd_grid(const float* __restr
     reinterpret_cast<float2*>(d_grid)[(long)b * Ho * Wo + i] = o;
 }
 
+
+// ---- A15: axis-angle + translation -> 4x4 transformation (layers.py:26-42, 61-100) --------------------------------------
+// One thread per sample.  The reference builds the matrix from ~25 tiny element-wise kernels (and autograd adds ~50 more on
+// the way back) on the step's critical stream; here the forward is one launch and the backward one launch whose Jacobian
+// comes from running the SAME arithmetic on dual numbers (value + 6 partial derivatives): exact, no hand-derived formulas.
+struct Dual6 {
+    float v, d[6];
+};
+__device__ __forceinline__ Dual6 dconst(float c) { Dual6 r; r.v = c; for (int i = 0; i < 6; ++i) r.d[i] = 0.f; return r; }
+__device__ __forceinline__ Dual6 dvar(float c, int k) { Dual6 r = dconst(c); r.d[k] = 1.f; return r; }
+__device__ __forceinline__ Dual6 operator+(const Dual6& a, const Dual6& b) { Dual6 r; r.v = a.v + b.v; for (int i = 0; i < 6; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ Dual6 operator-(const Dual6& a, const Dual6& b) { Dual6 r; r.v = a.v - b.v; for (int i = 0; i < 6; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ Dual6 operator*(const Dual6& a, const Dual6& b) { Dual6 r; r.v = a.v * b.v; for (int i = 0; i < 6; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ Dual6 operator/(const Dual6& a, const Dual6& b) {
+    Dual6 r; r.v = a.v / b.v;
+    for (int i = 0; i < 6; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v;
+    return r;
+}
+__device__ __forceinline__ Dual6 dsqrt(const Dual6& a) { Dual6 r; r.v = sqrtf(a.v); for (int i = 0; i < 6; ++i) r.d[i] = a.v > 0.f ? a.d[i] / (2.f * r.v) : 0.f; return r; }
+__device__ __forceinline__ Dual6 dsin(const Dual6& a) { Dual6 r; r.v = sinf(a.v); const float c = cosf(a.v); for (int i = 0; i < 6; ++i) r.d[i] = c * a.d[i]; return r; }
+__device__ __forceinline__ Dual6 dcos(const Dual6& a) { Dual6 r; r.v = cosf(a.v); const float s = -sinf(a.v); for (int i = 0; i < 6; ++i) r.d[i] = s * a.d[i]; return r; }
+
+// T[16] row-major from (axis-angle vx, vy, vz, translation tx, ty, tz); `N` is float (forward) or Dual6 (backward)
+template <typename N>
+__device__ __forceinline__ void pose_matrix(const N& vx, const N& vy, const N& vz, const N& tx, const N& ty, const N& tz, int invert,
+                                            N (&T)[16], N (*cst)(float), N (*sq)(const N&), N (*sn)(const N&), N (*cs)(const N&)) {
+    const N angle = sq(vx * vx + vy * vy + vz * vz);
+    const N den = angle + cst(1e-7f);
+    const N x = vx / den, y = vy / den, z = vz / den;
+    const N ca = cs(angle), sa = sn(angle);
+    const N C = cst(1.f) - ca;
+    const N xC = x * C, yC = y * C, zC = z * C;
+    N R[9] = {x * xC + ca, x * yC - z * sa, z * xC + y * sa,
+              x * yC + z * sa, y * yC + ca, y * zC - x * sa,
+              z * xC - y * sa, y * zC + x * sa, z * zC + ca};
+    const N zero = cst(0.f), one = cst(1.f);
+    if (!invert) {                                           // T(t) . R  = [R | t]
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) T[4 * i + j] = R[3 * i + j];
+        }
+        T[3] = tx; T[7] = ty; T[11] = tz;
+    } else {                                                 // R^T . T(-t) = [R^T | -R^T t]
+        const N nx = zero - tx, ny = zero - ty, nz = zero - tz;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) T[4 * i + j] = R[3 * j + i];
+            T[4 * i + 3] = R[i] * nx + R[3 + i] * ny + R[6 + i] * nz;
+        }
+    }
+    T[12] = zero; T[13] = zero; T[14] = zero; T[15] = one;
+}
+__device__ __forceinline__ float fconst(float c) { return c; }
+__device__ __forceinline__ float fsqrt(const float& a) { return sqrtf(a); }
+__device__ __forceinline__ float fsin(const float& a) { return sinf(a); }
+__device__ __forceinline__ float fcos(const float& a) { return cosf(a); }
+
+__global__ void pose_matrix_fwd(const float* __restrict__ aa, const float* __restrict__ tr, float* __restrict__ T, int B, int invert) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float M[16];
+    pose_matrix<float>(aa[3 * b], aa[3 * b + 1], aa[3 * b + 2], tr[3 * b], tr[3 * b + 1], tr[3 * b + 2], invert, M, fconst, fsqrt, fsin, fcos);
+    for (int i = 0; i < 16; ++i) T[16 * b + i] = M[i];
+}
+__global__ void pose_matrix_bwd(const float* __restrict__ aa, const float* __restrict__ tr, const float* __restrict__ dT,
+                                float* __restrict__ daa, float* __restrict__ dtr, int B, int invert) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    Dual6 M[16];
+    pose_matrix<Dual6>(dvar(aa[3 * b], 0), dvar(aa[3 * b + 1], 1), dvar(aa[3 * b + 2], 2), dvar(tr[3 * b], 3), dvar(tr[3 * b + 1], 4),
+                       dvar(tr[3 * b + 2], 5), invert, M, dconst, dsqrt, dsin, dcos);
+    float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 16; ++i) {
+        const float w = dT[16 * b + i];
+        for (int k = 0; k < 6; ++k) g[k] += w * M[i].d[k];
+    }
+    for (int k = 0; k < 3; ++k) { daa[3 * b + k] = g[k]; dtr[3 * b + k] = g[3 + k]; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -259,6 +336,23 @@ int ppea_grid_sample_bwd_grid_f32(const float* src, const float* grid, const flo
     dim3 g((Ho * Wo + 255) / 256, B);
     hipLaunchKernelGGL(grid_sample_bwd_grid, g, dim3(256), 0, (hipStream_t)stream, src, grid, d_out, d_grid,
                        C, Hi, Wi, Ho, Wo, padding);
+    return launch_status();
+}
+
+
+// A15 (layers.py:26-42, 61-100): T [B][4][4] fp32 from axis-angle aa [B][3] and translation tr [B][3] (invert: the inverse
+// transformation R^T T(-t)); backward: d aa, d tr from dT (exact Jacobian of the same arithmetic).
+int ppea_pose_matrix_fwd_f32(const float* aa, const float* tr, float* T, int B, int invert, void* stream) {
+    if (B < 0) return PPEA_ERR_ARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(pose_matrix_fwd, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, aa, tr, T, B, invert);
+    return launch_status();
+}
+int ppea_pose_matrix_bwd_f32(const float* aa, const float* tr, const float* dT, float* daa, float* dtr, int B, int invert,
+                             void* stream) {
+    if (B < 0) return PPEA_ERR_ARG;
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(pose_matrix_bwd, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, aa, tr, dT, daa, dtr, B, invert);
     return launch_status();
 }
 

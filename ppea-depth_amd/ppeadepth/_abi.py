@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libppea_depth.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -104,6 +104,8 @@ SIGNATURES = {
     "ppea_backproject_project_bwd_f32": [_vp] * 7 + [_i] * 3 + [_f, _vp],
     "ppea_grid_sample_fwd_f32": [_vp] * 3 + [_i] * 7 + [_vp],
     "ppea_grid_sample_bwd_grid_f32": [_vp] * 4 + [_i] * 7 + [_vp],
+    "ppea_pose_matrix_fwd_f32": [_vp, _vp, _vp, _i, _i, _vp],
+    "ppea_pose_matrix_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "ppea_ssim_l1_fwd_f32": [_vp, _vp, _vp, _l] + [_i] * 4 + [_f, _vp],
     "ppea_ssim_l1_bwd_f32": [_vp, _vp, _vp, _l, _vp] + [_i] * 4 + [_f, _vp],
     "ppea_smooth_num_partials": [],

@@ -46,8 +46,15 @@ def get_translation_matrix(translation_vector):
     return T
 
 
+POSE_MATRIX_KERNEL = __import__("os").environ.get("PPEA_POSE_KERNEL", "1") == "1"
+
+
 def transformation_from_parameters(axisangle, translation, invert=False):
-    """layers.py:26-42."""
+    """layers.py:26-42.  On the device: one launch (csrc/geometry.hip pose_matrix_*) -- and fp32 throughout: under bf16
+    autocast the composite below would run its two 4x4 matmuls in bf16."""
+    if POSE_MATRIX_KERNEL and axisangle.is_cuda and axisangle.dim() == 3 and axisangle.shape[1] == 1:
+        from . import ops
+        return ops.pose_matrix(axisangle, translation, invert)
     R = rot_from_axisangle(axisangle)
     t = translation.clone()
     if invert:

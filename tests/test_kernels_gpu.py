@@ -683,6 +683,34 @@ def test_adam_flat_matches_torch_adam(device):
     assert torch.equal(W16, P[:n_lo].bfloat16())
 
 
+@pytest.mark.parametrize("invert", [False, True])
+def test_pose_matrix_kernel_equals_the_composite(device, invert):
+    """A15 `transformation_from_parameters` (layers.py:26-42, 61-100) as one launch per direction: the matrix and the
+    gradients of axis-angle and translation against the element-wise composite in fp32 (the backward's Jacobian comes from
+    the same arithmetic on dual numbers), incl. small and zero rotation angles."""
+    from ppeadepth import layers
+    g = _g(3 + int(invert))
+    aa = (torch.randn(12, 1, 3, generator=g) * torch.tensor([1e-3, 1e-2, 0.1, 1.0] * 3).view(12, 1, 1))
+    aa[5] = 0.0
+    tr = torch.randn(12, 1, 3, generator=g)
+    go = torch.randn(12, 4, 4, generator=g)
+    res = []
+    for kernel in (False, True):
+        layers.POSE_MATRIX_KERNEL = kernel
+        try:
+            a = aa.clone().to(device).requires_grad_(True)
+            t = tr.clone().to(device).requires_grad_(True)
+            T = layers.transformation_from_parameters(a, t, invert)
+            (T * go.to(device)).sum().backward()
+            res.append((T.detach().cpu(), a.grad.cpu(), t.grad.cpu()))
+        finally:
+            layers.POSE_MATRIX_KERNEL = True
+    ok = [i for i in range(12) if i != 5]                    # (the composite's own gradient at a zero angle is NaN / 0-0)
+    assert (res[1][0] - res[0][0]).abs().max() < 2e-6
+    assert rel_err(res[1][1][ok], res[0][1][ok]) < 1e-4 and rel_err(res[1][2], res[0][2]) < 1e-5
+    assert torch.isfinite(res[1][1]).all()
+
+
 def test_adam_flat_scaled_divides_rank_summed_gradients(device):
     """Several ranks: the exchange leaves the SUM of the gradients over the ranks in the flat buffer and the Adam kernel
     multiplies by 1 / world as it reads them -- bit-identical to a separate scaling pass followed by the plain kernel."""
