@@ -28,11 +28,12 @@ class Census(TorchFunctionMode):
     def __torch_function__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
         t = out[0] if isinstance(out, (tuple, list)) and out and torch.is_tensor(out[0]) else out
-        if torch.is_tensor(t) and t.is_cuda and t.numel() <= 4096:
+        if torch.is_tensor(t) and t.is_cuda and t.numel() <= int(os.environ.get('MAX_NUMEL', '4096')):
             name = getattr(func, "__name__", str(func))
             if name not in ("view", "reshape", "__getitem__", "detach", "size", "dim", "to", "float", "contiguous", "unsqueeze",
                             "squeeze", "expand", "permute", "transpose", "t", "view_as", "__get__", "data_ptr", "is_contiguous",
-                            "stride", "numel", "type", "requires_grad_", "unbind", "chunk", "split", "flatten", "narrow", "select"):
+                            "stride", "numel", "type", "requires_grad_", "unbind", "chunk", "split", "flatten", "narrow", "select", "empty",
+                            "empty_like", "apply", "record_stream", "is_floating_point", "element_size", "storage_offset"):
                 site = "?"
                 for fr in reversed(traceback.extract_stack()[:-1]):
                     if "ppeadepth" in fr.filename:
