@@ -40,17 +40,21 @@ LAYERS = [  # name, N, Cin, H, W, Cout, k, stride, pad, reflect, act, bias, coun
 ]
 
 
-def timeit(fn, n=20):
+def timeit(fn, n=20, reps=3):
+    """Median of `reps` event-bracketed batches of n calls: one host hiccup in a batch must not become the layer's figure."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(n):
-        fn()
-    e.record()
-    e.synchronize()
-    return s.elapsed_time(e) / n * 1e3
+    out = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            fn()
+        e.record()
+        e.synchronize()
+        out.append(s.elapsed_time(e) / n * 1e3)
+    return sorted(out)[reps // 2]
 
 
 def main():
