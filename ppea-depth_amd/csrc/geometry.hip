@@ -345,6 +345,7 @@ int ppea_grid_sample_bwd_grid_f32(const float* src, const float* grid, const flo
 int ppea_pose_matrix_fwd_f32(const float* aa, const float* tr, float* T, int B, int invert, void* stream) {
     if (B < 0) return PPEA_ERR_ARG;
     if (B == 0) return 0;
+    if (!aa || !tr || !T) return PPEA_ERR_ARG;
     hipLaunchKernelGGL(pose_matrix_fwd, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, aa, tr, T, B, invert);
     return launch_status();
 }
@@ -352,6 +353,7 @@ int ppea_pose_matrix_bwd_f32(const float* aa, const float* tr, const float* dT, 
                              void* stream) {
     if (B < 0) return PPEA_ERR_ARG;
     if (B == 0) return 0;
+    if (!aa || !tr || !dT || !daa || !dtr) return PPEA_ERR_ARG;
     hipLaunchKernelGGL(pose_matrix_bwd, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, aa, tr, dT, daa, dtr, B, invert);
     return launch_status();
 }

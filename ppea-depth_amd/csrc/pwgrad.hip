@@ -472,7 +472,9 @@ int ppea_pwgrad_ex_pair_bf16(const void* const* P, const void* const* Q, void* w
                              int HW, void* const* out_w, const int* out_w_bf16, const int* taps, void* const* out_b,
                              const int* out_b_bf16, const int* b_row0, const int* b_rows, void* stream) {
     if (B <= 0 || HW <= 0 || pwgrad_bk(HW) != 32) return PPEA_ERR_UNSUPPORTED;
+    if (workspace == nullptr) return PPEA_ERR_ARG;
     for (int k = 0; k < 2; ++k) {
+        if (P[k] == nullptr || Q[k] == nullptr) return PPEA_ERR_ARG;
         if (M[k] <= 0 || N[k] <= 0 || taps[k] < 1 || (M[k] % taps[k]) != 0) return PPEA_ERR_UNSUPPORTED;
         if (out_w[k] == nullptr || (out_b[k] != nullptr && (b_row0[k] < 0 || b_row0[k] + b_rows[k] > M[k]))) return PPEA_ERR_ARG;
     }
