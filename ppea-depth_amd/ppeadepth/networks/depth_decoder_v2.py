@@ -4,7 +4,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..layers import ConvBlock, Conv3x3, upsample, upsample_cat
+from ..layers import ConvBlock, Conv3x3, upsample_cat
 
 
 NHWC = True

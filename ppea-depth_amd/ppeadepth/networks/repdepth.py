@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from .. import rng
 from ..batchnorm import DeferredStats, set_deferred
-from ..layers import disp_to_depth, transformation_from_parameters
+from ..layers import transformation_from_parameters
 from .depth_decoder_v2 import DepthDecoderV2
 from .pose_decoder import PoseDecoder
 from .replk_matching_adapter import RepLKMatchingAdapter
