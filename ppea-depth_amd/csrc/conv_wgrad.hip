@@ -228,7 +228,7 @@ __global__ __launch_bounds__(1024) void conv_wgrad_reduce_kernel(const float* __
     }
 }
 
-// few slabs (large-channel layers: many elements, 1-8 slabs): one thread per element, serial sum
+// few slabs (large-channel layers: many elements, 1-16 slabs): one thread per element, serial sum
 __global__ void conv_wgrad_reduce_flat_kernel(const float* __restrict__ ws, void* __restrict__ dw, int dw_bf16, int slabs,
                                               int RS, int Cout, int Cin, int CoutP, int CinP) {
     const long total = (long)Cout * Cin * RS;
@@ -276,7 +276,11 @@ WgPlan plan(int N, int Cin, int Cout, int K, int stride, int Ho, int Wo) {
     // ... except that a layer never runs as fewer workgroups than CUs for want of workspace: 1024 -> 512 (19 MB per slab,
     // 128 tiles) ran as 128 workgroups walking 48 patches each -- 307 us against the library's 153; with 4 splits 184 us.
     // (More slabs everywhere -- a 128 MB cap -- was a net loss: every slab is a full-size fp32 gradient written and re-read.)
-    const long floor_splits = want < 4 ? want : 4;
+    // (the same for the layers whose cap leaves them a few workgroups short of one per CU: 512 -> 256 at 24 x 80 ran as
+    // 192 workgroups, 256 -> 128 at 48 x 160 as 216)
+    long floor_splits = want < 4 ? want : 4;
+    const long fill = (256 + tiles - 1) / tiles;
+    if (fill <= want && fill > floor_splits && fill * 3 <= cap * 4) floor_splits = fill;
     if (splits < floor_splits) splits = floor_splits;
     if (splits > p.n_patches) splits = p.n_patches;
     if (splits < 1) splits = 1;
@@ -338,7 +342,7 @@ int ppea_conv_wgrad_nhwc_bf16(const void* dz, const void* x, void* dw, int dw_bf
     int err = launch_status();
     if (err) return err;
     const long total = (long)Cout * Cin * R * S;
-    if (p.slabs >= 16) {
+    if (p.slabs > 16) {
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64, 16), 0, st,
                            (const float*)workspace, dw, dw_bf16, p.slabs, R * S, Cout, Cin, p.CoutP, p.CinP);
     } else {
