@@ -40,6 +40,27 @@ def test_product_fails_loudly_without_hip_device():
         ops.ssim_l1(torch.rand(1, 3, 8, 8), torch.rand(1, 3, 8, 8))
 
 
+def test_conv_weight_gradient_plan_fills_the_compute_units():
+    """Host planning of ppea_conv_wgrad_nhwc_bf16 (no device call): workspace = slabs x [K*K][CoutP][CinP] fp32.  A layer that
+    the 32 MB workspace cap would leave a few workgroups short of one per CU takes the extra splits (512 -> 256 at 24 x 80:
+    32 tiles x 8 splits = 256 workgroups, not 6 -> 192; 256 -> 128 at 48 x 160: 8 x 32, not 27 -> 216); a layer that is
+    far from it keeps the cap's floor (1024 -> 512 at 12 x 40: 128 tiles x 4); small layers are not touched."""
+    from ppeadepth import _abi
+    ws = _abi.lib.ppea_conv_wgrad_workspace_bytes
+
+    def slabs(N, Cin, Cout, K, stride, Ho, Wo):
+        per_slab = K * K * ((Cout + 63) // 64 * 64) * ((Cin + 63) // 64 * 64) * 4
+        b = ws(N, Cin, Cout, K, K, stride, Ho, Wo)
+        assert b > 0 and b % per_slab == 0
+        return b // per_slab
+
+    assert slabs(12, 512, 256, 3, 1, 24, 80) == 8
+    assert slabs(12, 256, 128, 3, 1, 48, 160) == 32
+    assert slabs(12, 1024, 512, 3, 1, 12, 40) == 4
+    assert slabs(12, 64, 64, 3, 1, 96, 320) * 1 >= 256          # one 64 x 64 tile: every split is a workgroup
+    assert ws(12, 64, 64, 3, 2, 1, 48, 160) == 0                # R != S: not served
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "ppea-depth_amd")
     for d, _, files in os.walk(pkg):
