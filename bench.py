@@ -245,10 +245,12 @@ def main():
     head_start(250)
     ops.PROFILE_DWCONV = []                       # (kind, start_event, end_event) per k=31 launch
     ops.SYNC_COUNTERS = {}                        # SyncBN launches / collectives of this one eager step
+    pdist.COLLECTIVE_LOG = []                     # (communicator, op, elements, dtype) of every collective, in issue order
     engine.step(dict(inputs))
     barrier()
     events, ops.PROFILE_DWCONV = ops.PROFILE_DWCONV, None
     sync_counts, ops.SYNC_COUNTERS = ops.SYNC_COUNTERS, None
+    coll_log, pdist.COLLECTIVE_LOG = pdist.COLLECTIVE_LOG, None
     # the same launch (same tensors, same stream) 20x back to back between two HIP events: the kernel's duration
     # without the host gaps that events around ONE ~80 us launch include
     replay_us = {}
@@ -337,6 +339,33 @@ def main():
     # Several ranks: the captured step also holds the RCCL calls (SyncBN all-gathers / all-reduces on per-branch
     # communicators, the gradient all-reduce on a side stream).  Capture is attempted on every rank; if any
     # rank fails, all fall back to eager launches (PPEA_MULTI_GRAPH=0 skips the attempt).
+    def rccl_census():
+        """What RCCL saw in one step (the probe step's host-side log; the captured graph replays the same sequence):
+        ranks, communicators, collectives and bytes per step, gradient ranges.  None without a process group."""
+        if not pdist.collectives_on():
+            return None
+        esz = {"float32": 4, "bfloat16": 2, "float16": 2, "float64": 8, "int32": 4, "int64": 8}
+        per = {}
+        for key, op, numel, dtype in coll_log:
+            d = per.setdefault(key, {"collectives": 0, "bytes": 0, "ops": {}})
+            d["collectives"] += 1
+            d["bytes"] += numel * esz.get(dtype, 4)
+            d["ops"][op] = d["ops"].get(op, 0) + 1
+        plan = engine.flat.last_plan if (engine.flat is not None and engine.flat.hooked) else []
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                        # noqa: BLE001
+            ver = None
+        return {"world": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": ver,
+                "communicators": sorted(per), "per_communicator": per,
+                "collectives_per_step": sum(d["collectives"] for d in per.values()),
+                "bytes_per_step": sum(d["bytes"] for d in per.values()),
+                "grad_ranges": len(plan), "grad_ranges_from_hooks": sum(1 for p in plan if p[3]),
+                "grad_bytes_per_step": sum(p[2] for p in plan) * 4,
+                "forced_single_rank": bool(pdist.FORCE_COLLECTIVES and world == 1),
+                "order_check": "per-communicator issue order equal across ranks and eager == capture: "
+                               "tests/test_ddp_gpu.py::test_collective_order_*, test_forced_collectives_*"}
+
     def make_line(dt, loss_val, launch):
         # ---- roofline of the 31x31 depthwise conv (fwd launches with the fused 5x5 branch) ------
         es = 2 if args.dtype == "bf16" else 4
@@ -415,6 +444,7 @@ def main():
                          "collectives_per_step": sync_counts.get("collectives", 0),
                          "forced_single_rank": bool(pdist.FORCE_COLLECTIVES and world == 1)}
                         if pdist.collectives_on() else None),
+            "rccl": rccl_census(),
             "roofline": roof,
             "roofline_pwconv": pw_roof,
         }

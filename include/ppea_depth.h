@@ -440,6 +440,28 @@ int ppea_conv_wgrad_nhwc_bf16(const void* dz, const void* x, void* dw, int dw_bf
 int ppea_image_to_nhwc_bf16(const float* x, void* y, int N, int C, int H, int W, int Cp, float sub, float div,
                             void* stream);
 
+/* fp32 dense convolutions / linear layers on the fp32 matrix cores (csrc/conv_f32.hip, v_mfma_f32_32x32x2_f32): the
+ * fp32 (parity, BASELINE config 1) step's replacement for every library convolution and GEMM behind
+ *   RepLKBlock / ConvFFN 1x1 convs, B_Adapter / Adapter     networks/replknet_adapter.py:20-109, 264-326
+ *   ConvBlock / Conv3x3 / ConvTranspose2d (Stage 2)          layers.py:103-135, networks/depth_decoder_v2.py:172-245
+ *   ResNet-18 pose trunk, PoseDecoder                        networks/resnet_encoder.py:367-409, networks/pose_decoder.py:27-52
+ *   reduce_conv, RepLKNet stem[0]                            networks/replk_matching_adapter.py:127-131, replknet_adapter.py:411
+ * One implicit-GEMM family for every kernel size, stride, zero padding and memory format: x / y / dy / dx are addressed
+ * through four ELEMENT strides (n, c, h, w) -- NCHW, channels_last, or a [tokens][features] matrix viewed as
+ * [1][features][tokens][1] (nn.Linear).  w / dw: [Cout][Cin][R][S] contiguous.  Ho = (H + 2 pad - R) / stride + 1.
+ *   ppea_conv2d_f32_fwd     y = bias + conv(x)  (bias [Cout] or NULL)
+ *   ppea_conv2d_f32_dgrad   dx (every element written) from dy
+ *   ppea_conv2d_f32_wgrad   dw = sum over pixels, split over the grid with fp32 slabs in a caller-owned workspace of
+ *                           ppea_conv2d_f32_wgrad_workspace_bytes(...) bytes summed in a fixed order (no atomics)
+ * ---------------------------------------------------------------------------------------- */
+int ppea_conv2d_f32_fwd(const float* x, const long* xs, const float* w, const float* bias, float* y, const long* ys, int N,
+                        int Cin, int H, int W, int Cout, int R, int S, int stride, int pad, void* stream);
+int ppea_conv2d_f32_dgrad(const float* dy, const long* dys, const float* w, float* dx, const long* dxs, int N, int Cin, int H,
+                          int W, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, void* stream);
+long ppea_conv2d_f32_wgrad_workspace_bytes(int N, int Cin, int Cout, int R, int S, int Ho, int Wo);
+int ppea_conv2d_f32_wgrad(const float* x, const long* xs, const float* dy, const long* dys, float* dw, float* workspace, int N,
+                          int Cin, int H, int W, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, void* stream);
+
 /* Image-fed convolutions (csrc/conv_image.hip): RepLKNet stem[0] (networks/replknet_adapter.py:411, 3x3 stride 2) and
  * the pose ResNet-18 conv1 (networks/resnet_encoder.py:376-388, 7x7 stride 2).  The frame is channels-last bf16 with its
  * 3 / 6 channels zero-padded to 8 (ppea_image_to_nhwc_bf16); one MFMA contraction covers a whole filter ROW (S taps x 8

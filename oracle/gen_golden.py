@@ -376,6 +376,11 @@ GENERATORS = {
     # trunk, predicted pose = rendered pose; config 1/2's model at full size.  The bf16 step is held to absolute bounds
     # on it (tests/test_e2e_gpu.py::test_engine_step_bf16_on_the_rendered_fixture)
     "e2e_render": lambda: gen_e2e("e2e_render", 2, 192, 640, stride=8, conditioned=True),
+    # the same well-conditioned construction for BASELINE config 4's model (RepLKNet-31L) at full size and for config 5
+    # (Stage-2 `--dc`, 192x512, Cityscapes intrinsics): absolute bounds for the bf16 step of every benchmarked model
+    "e2e_render_l": lambda: gen_e2e("e2e_render_l", 2, 192, 640, extra=["--rep_size", "l"], stride=8, conditioned=True),
+    "e2e_render_dc": lambda: gen_e2e("e2e_render_dc", 2, 192, 512, extra=["--dc"], stride=8, grad_keys=DC_GRAD_KEYS,
+                                     intrinsics="cityscapes", conditioned=True),
 }
 
 

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libppea_depth.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -148,6 +148,10 @@ SIGNATURES = {
     "ppea_pwconv_stats_partials": [_i] * 4,
     "ppea_pwconv_stats_bf16": [_vp] * 5 + [_i] * 4 + [_vp],
     "ppea_bn_finalize_sums_f32": [_vp, _i, _i, ctypes.c_long, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ppea_conv2d_f32_fwd": [_vp] * 6 + [_i] * 9 + [_vp],
+    "ppea_conv2d_f32_dgrad": [_vp] * 5 + [_i] * 11 + [_vp],
+    "ppea_conv2d_f32_wgrad_workspace_bytes": [_i] * 7,
+    "ppea_conv2d_f32_wgrad": [_vp] * 6 + [_i] * 11 + [_vp],
     "ppea_cost_volume_fwd_f32": [_vp] * 7 + [_i] * 5 + [_f, _vp],
     "ppea_cost_volume_reduce_f32": [_vp] * 6 + [_i] * 4 + [_vp],
 }

@@ -84,6 +84,11 @@ def _collectives_on():
     return collectives_on()
 
 
+def _log_collective(op, tensor, group):
+    from .dist import log_collective
+    log_collective(op, tensor, group)
+
+
 class _SyncBNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, group):
@@ -94,6 +99,7 @@ class _SyncBNFn(torch.autograd.Function):
         packed = torch.cat([mean, invstd, mean.new_full((1,), float(count))])
         world = dist.get_world_size(group)
         gathered = torch.empty(world, 2 * C + 1, device=x.device, dtype=packed.dtype)
+        _log_collective("all_gather", gathered, group)
         dist.all_gather(list(gathered.unbind(0)), packed, group=group)
         mean_all, invstd_all, counts = gathered[:, :C], gathered[:, C:2 * C], gathered[:, 2 * C]
         mean, invstd = torch.batch_norm_gather_stats_with_counts(
@@ -112,6 +118,7 @@ class _SyncBNFn(torch.autograd.Function):
             dy, x, mean, invstd, weight, True, True, True)
         C = sum_dy.shape[0]
         packed = torch.cat([sum_dy, sum_dy_xmu])
+        _log_collective("all_reduce", packed, ctx.group)
         dist.all_reduce(packed, group=ctx.group)
         sum_dy, sum_dy_xmu = packed[:C], packed[C:]
         dx = torch.batch_norm_backward_elemt(dy, x, mean, invstd, weight, sum_dy, sum_dy_xmu, counts)
@@ -196,11 +203,11 @@ def _book_sync(bns, st, z):
                 _ACTIVE_DEFERRED.add(bn, st[2 * k], st[2 * k + 1], cnt)
 
 
-def assign_groups(model):
+def assign_groups(model, any_backend=False):
     """One process group per concurrently running branch: ProcessGroupNCCL runs a group's collectives in order
     on one internal stream, so the teacher's and the student's SyncBN exchanges must not share a group or the
     two branches of the step serialise on it.  Call on every rank, after init_process_group."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_backend() != "nccl" and not any_backend):
         return
     groups = {}
     for top in ("mono_encoder", "encoder"):

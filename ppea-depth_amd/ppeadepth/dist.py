@@ -54,21 +54,41 @@ def init_distributed(backend=None):
 COMM = {}
 _COMM_OF_BRANCH = {"depth": "encoder", "encoder": "encoder", "pose": "encoder", "mono_depth": "mono_encoder",
                    "mono_encoder": "mono_encoder", "encoder_adapters": "adapters"}
+_KEY_OF = {}              # id(process group) -> communicator key ("encoder" / "mono_encoder" / "adapters"); else "world"
+
+# Tests / bench.py: while this is a list, every collective the step issues appends (communicator key, op, elements,
+# dtype) to it in HOST ISSUE ORDER -- the order in which ProcessGroupNCCL enqueues the communicator's kernels on its
+# internal stream, eager or under capture.  RCCL requires that order to be the same on every rank, per communicator
+# (tests/test_ddp_gpu.py::test_collective_order_*; bench.py reports the per-step census as the `rccl` object).
+COLLECTIVE_LOG = None
 
 
-def assign_groups(model):
-    """Create the per-branch communicators (RCCL only; gloo serialises on the host anyway) and hand the SyncBN layers
-    theirs.  Call on every rank, after init_process_group, before the first step."""
+def key_of(group):
+    return "world" if group is None else _KEY_OF.get(id(group), "world")
+
+
+def log_collective(op, tensor, group=None):
+    if COLLECTIVE_LOG is not None:
+        COLLECTIVE_LOG.append((key_of(group), op, int(tensor.numel()), str(tensor.dtype).replace("torch.", "")))
+
+
+def assign_groups(model, any_backend=False):
+    """Create the per-branch communicators and hand the SyncBN layers theirs.  Call on every rank, after
+    init_process_group, before the first step.  RCCL only by default (gloo serialises on the host anyway);
+    `any_backend` builds the same communicator layout on gloo (the collective-order tests)."""
     from . import batchnorm
     COMM.clear()
-    groups = batchnorm.assign_groups(model)
+    _KEY_OF.clear()
+    groups = batchnorm.assign_groups(model, any_backend)
     if groups:
         COMM.update(groups)
         COMM["adapters"] = dist.new_group()
+        _KEY_OF.update({id(g): k for k, g in COMM.items()})
     return COMM
 
 
 def comm_of(branch):
+    """The communicator of a gradient range: a pure function of the range's branch (never of where it is launched)."""
     return COMM.get(_COMM_OF_BRANCH.get(branch, "encoder"))
 
 
@@ -216,8 +236,14 @@ class FlatGrads:
         hi = self.offsets[b] if b < len(self.offsets) else self.numel
         if collectives_on():
             chunk = self.flat[lo:hi]
-            # from a hook: the communicator of the stream that produced the range; after backward: the step stream's
-            dist.all_reduce(chunk, group=comm_of("encoder" if after_backward else self._range_branch[k]))
+            # ALWAYS the communicator of the range's branch -- from a hook (on the stream that produced the range) and
+            # after backward (on the step stream, which autograd has joined with every stream it used) alike.  A range that
+            # one rank launches from a hook and another from finish() (a rank-dependent unused parameter) thus still meets
+            # its peers on the same communicator, and ProcessGroupNCCL orders it on that communicator's internal stream
+            # by host issue order either way.
+            group = comm_of(self._range_branch[k])
+            log_collective("all_reduce", chunk, group)
+            dist.all_reduce(chunk, group=group)
             if not self.scale_in_optimizer:        # (the flat Adam kernel multiplies by 1 / world as it reads the sums)
                 chunk.mul_(1.0 / world_size())
 
@@ -244,12 +270,14 @@ class FlatGrads:
             with torch.cuda.stream(self.comm_stream):
                 for a, b in zip(self.bounds[:-1], self.bounds[1:]):
                     chunk = self.flat[a:b]
+                    log_collective("all_reduce", chunk)
                     dist.all_reduce(chunk)
                     chunk.mul_(1.0 / w)
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
             for a, b in zip(self.bounds[:-1], self.bounds[1:]):
                 chunk = self.flat[a:b]
+                log_collective("all_reduce", chunk)
                 dist.all_reduce(chunk)
                 chunk.mul_(1.0 / w)
 
@@ -309,8 +337,15 @@ class TrainEngine:
             self._hi = [self.masters[id(p)] for p in self._lo]
         self.flat = FlatGrads(self.opt_params, n_chunks, align=128 if self.flat_adam else 1) \
             if (collectives_on() or self.flat_adam) else None
+        # Gradient scale read by the flat Adam kernel: fixed HERE, with the world size of construction time (it
+        # was re-derived from collectives_on() at every step and could disagree with what the exchange had left).
+        self.grad_scale = 1.0
         if self.flat is not None and self.flat_adam and collectives_on() and OVERLAP_ALLREDUCE:
-            self.flat.scale_in_optimizer = True        # .grad holds the SUM over ranks; the optimizer kernel divides
+            # CONTRACT: with this flag `p.grad` / `FlatGrads.flat` hold the SUM over ranks after a step, not the mean; the
+            # optimizer kernel multiplies by `grad_scale` = 1 / world as it reads them.  Readers that want DDP's mean
+            # gradients (logging, clipping, export) use `mean_grads()`.
+            self.flat.scale_in_optimizer = True
+            self.grad_scale = 1.0 / world_size()
         if self.flat is not None and collectives_on() and OVERLAP_ALLREDUCE:
             # gradient exchange overlapped with backward, one range per (branch of the step, dtype class)
             names = {id(p): n for n, p in model.named_parameters()}
@@ -398,7 +433,7 @@ class TrainEngine:
         g = self.optimizer.param_groups[0]
         with torch.no_grad():
             self.adam_state[0] += 1
-        gscale = 1.0 / world_size() if (self.flat.scale_in_optimizer and collectives_on()) else 1.0
+        gscale = self.grad_scale
         call("ppea_adam_flat_scaled_f32", ptr(self.P), ptr(self.flat.flat), ptr(self.M), ptr(self.V),
              ptr(self.W16) if self.n_lo else None, self.flat.numel, self.n_lo, ptr(self.adam_state),
              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), gscale, stream_ptr())
@@ -410,10 +445,20 @@ class TrainEngine:
     # reference's learning rate drops every ceil(15 / 8) = 2 epochs, not every 15.  PRESERVED by default (a drop-in
     # replacement must train with the reference's schedule under the same launch); `lr_quirk=False` steps once per call
     # (the schedule the options describe).
-    def scheduler_step(self, lr_quirk=True):
+    def scheduler_step(self, lr_quirk=None):
+        if lr_quirk is None:
+            lr_quirk = bool(getattr(self.trainer.opt, "lr_quirk", True))
         for _ in range(world_size() if lr_quirk else 1):
             self.scheduler.step()
         self.sync_lr()
+
+    def describe_schedule(self):
+        """One line for the start-up log: the learning-rate schedule this launch will actually follow."""
+        quirk = bool(getattr(self.trainer.opt, "lr_quirk", True))
+        w = world_size() if quirk else 1
+        every = -(-self.trainer.opt.scheduler_step_size // w)
+        return (f"StepLR x0.1 every {every} epoch(s) (scheduler_step_size {self.trainer.opt.scheduler_step_size}, {world_size()} rank(s), "
+                f"lr_quirk={'on: Accelerate steps the schedule once per rank' if quirk else 'off'})")
 
     def sync_lr(self):
         """Push the optimizer's (scheduled) learning rate into the device scalar the step kernel reads."""
@@ -496,8 +541,13 @@ class TrainEngine:
         self.trainer.depth_bin_tracker.updated = snap[1]
         torch.cuda.synchronize()
 
+    def mean_grads(self):
+        """name -> gradient of this step as DDP would leave it (mean over ranks), whatever the exchange stored."""
+        return {n: (g * self.grad_scale if self.grad_scale != 1.0 else g) for n, g in self.named_grads().items()}
+
     def named_grads(self):
-        """name -> fp32 gradient of this step for every trainable parameter (the flat buffer's views)."""
+        """name -> fp32 gradient of this step for every trainable parameter (the flat buffer's views; the SUM over ranks
+        when `flat.scale_in_optimizer` is set -- see `mean_grads`)."""
         model = self.trainer._module()
         names = {id(p): n for n, p in model.named_parameters()}
         if self.flat is not None:

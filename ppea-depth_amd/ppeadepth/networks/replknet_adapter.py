@@ -35,7 +35,7 @@ def get_bn(channels):
 
 ADAPTER_STREAMS = os.environ.get("PPEA_ADAPTER_STREAMS", "1") == "1"   # adapters of the student on a forked side stream
 _SIDE = {}
-_DUP_FORK = os.environ.get("PPEA_DUP_FORK", "0") == "1"      # (debug: the alias for forked adapters too)
+_DUP_FORK_DEBUG = False      # set by tools/graph_edges_dup.py ONLY: the alias for forked adapters too
 NO_FORK_ON = set()       # cuda_stream handles on which adapters run inline (already a forked branch)
 
 
@@ -410,7 +410,7 @@ class ConvFFN(nn.Module):
             adpt, join = None, None
             if self.test_id >= 0:
                 if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
-                    adpt, join = _forked_adapter(self.mlp_adapter, second_use(out) if _DUP_FORK else out)
+                    adpt, join = _forked_adapter(self.mlp_adapter, second_use(out) if _DUP_FORK_DEBUG else out)
                 else:
                     # in line: hand the adapter the alias of `out` whose gradient joins pw1's inside the BatchNorm's backward
                     # launch (batchnorm.second_use).  NOT for the forked adapter: with the alias's gradient produced on the side
@@ -495,7 +495,7 @@ class RepLKBlock(nn.Module):
             adpt, join = None, None
             if self.test_id >= 0:
                 if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
-                    adpt, join = _forked_adapter(self.adapter, second_use(out) if _DUP_FORK else out)
+                    adpt, join = _forked_adapter(self.adapter, second_use(out) if _DUP_FORK_DEBUG else out)
                 else:
                     adpt = self.adapter(second_use(out))         # (see ConvFFN.forward)
             t = self._pw1_large_kernel_fused(out)

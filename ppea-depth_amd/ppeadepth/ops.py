@@ -825,7 +825,9 @@ def gather_rows(table, group):
     """ONE all-gather, IN PLACE: `table` [world, pitch] arrives with this rank's row filled (the statistics kernel wrote
     straight into it) and leaves with every rank's row -- no staging copy on either side of the collective."""
     import torch.distributed as dist
+    from .dist import log_collective
     mine = table[sync_rank(group)]
+    log_collective("all_gather", table, group)
     if dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(table, mine, group=group)
     else:
@@ -836,6 +838,8 @@ def gather_rows(table, group):
 def reduce_sums(sums, group):
     """ONE in-place all-reduce (sum) of a BatchNorm backward's [3][C] sums."""
     import torch.distributed as dist
+    from .dist import log_collective
+    log_collective("all_reduce", sums, group)
     dist.all_reduce(sums, group=group)
     _count(collectives=1)
 

@@ -42,6 +42,11 @@ class MonodepthOptions:
                      "trans", "input", "mono_trans", "mono_input", "pose_cnn", "loss_pct", "debug"):
             a("--" + flag, action="store_true")
         a("--selec_reproj", action="store_false")      # default True (options.py:428-430)
+        # NOT a reference flag.  Accelerate's wrapped StepLR steps once per RANK per scheduler.step() (accelerate
+        # scheduler.py:69-82), so the reference's learning rate drops every ceil(scheduler_step_size / ranks) epochs.
+        # Preserved by default (a drop-in must train on the reference's schedule); --no_lr_quirk gives the schedule the
+        # options describe.  TrainEngine.describe_schedule() prints the effective one.
+        a("--no_lr_quirk", dest="lr_quirk", action="store_false")
         self.parser = p
 
     def parse(self, argv=None):

@@ -60,9 +60,10 @@ class DepthBins:
     def compute(self):
         mn, mx = self.min_depth.float(), self.max_depth.float()
         import torch.distributed as dist
-        from .dist import collectives_on
+        from .dist import collectives_on, log_collective
         if collectives_on():
             pack = torch.stack([-mn.reshape(()), mx.reshape(())])
+            log_collective("all_reduce_max", pack)
             dist.all_reduce(pack, op=dist.ReduceOp.MAX)          # min via max of the negation
             mn, mx = -pack[0], pack[1]
         return mn, mx

@@ -618,3 +618,77 @@ def test_device_input_pipeline_feeds_process_batch(device):
     opt, model, tr = _build(device, B, H, W)
     outputs, losses = tr.process_batch(out_d, True)
     assert torch.isfinite(losses["loss"]).item() and outputs[("disp", 0)].shape == (B, 1, H, W)
+
+
+# ---- the benchmarked BATCH (B = 12, 192x640: BASELINE config 2) against the CPU oracle ---------------------------------
+# Tile dispatch depends on the batch (pw_choose's >= 256-workgroup rule, batch-major image groups of 16 in the depthwise
+# kernel, the weight-gradient split plan): every reference golden is B = 2, so the oracle (oracle/ref_model.py, pinned to
+# the reference by tests/test_oracle_golden.py) is run inside the test on the SAME B = 12 inputs.  Well-conditioned
+# construction of e2e_render (rendered frames, near-identity trunk, predicted pose = rendered pose): absolute bounds.
+B12_COS = ["depth.disp_convs.0.conv.weight", "depth.upconvs_0.0.conv.conv.weight", "mono_depth.upconvs_1.4.conv.conv.weight",
+           "encoder.replk.stages.0.blocks.1.mlp_adapter.D_fc2.weight", "encoder.replk.stages.2.blocks.10.adapter.D_fc2.weight"]
+
+
+@pytest.fixture(scope="module")
+def oracle_b12():
+    import types
+    from oracle import model_spec, ref_model
+    B, H, W = 12, 192, 640
+    popt = types.SimpleNamespace(rep_size="b", g_blk=1.0, g_ffn=1.0, use_checkpoint=False, height=H, width=W,
+                                 batch_size=B, num_depth_bins=96, min_depth=0.1, max_depth=100.0, disparity_smoothness=1e-3)
+    sd = {k: synth.synth_tensor(k, torch.empty(shape, dtype=dt), conditioned=True)
+          for k, (shape, dt) in model_spec.state_spec("b").items()}
+    sd = ref_model.leaf_state_dict(sd, popt)
+    ref = ref_model.RefTrainer(ref_model.RefRepDepth(sd, popt), popt)
+    inputs = synth.make_rendered_inputs(B, H, W)
+    torch.set_num_threads(min(torch.get_num_threads(), 16))
+    torch.manual_seed(5)
+    random.seed(5)
+    outputs, losses = ref.process_batch(dict(inputs))
+    losses["loss"].backward()
+    keep = {k: outputs[k].detach() for k in (("disp", 0), ("mono_disp", 0), ("cam_T_cam", 0, -1), ("cam_T_cam", 0, 1))}
+    grads = {k: sd[k].grad.detach().clone() for k in B12_COS}
+    return inputs, {k: v.detach() for k, v in losses.items()}, keep, grads
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_engine_step_at_the_benchmarked_batch_vs_cpu_oracle(device, oracle_b12, bf16):
+    """B = 12, 192x640, RepLKNet-31B: one TrainEngine step REPLAYED FROM THE hipGraph (the launch mode bench.py times) in
+    fp32 (1e-3, north_star) and in the benchmarked bf16 arithmetic (absolute bounds of the rendered fixture) against the
+    CPU oracle on identical inputs, weights and random draws: losses, disp / mono_disp, both cam_T_cam, five gradients."""
+    from ppeadepth import rng
+    from ppeadepth.dist import TrainEngine
+    inputs, ref_losses, ref_out, ref_grads = oracle_b12
+    B, H, W = 12, 192, 640
+    opt, model, tr = _build(device, B, H, W, amp=torch.bfloat16 if bf16 else None, conditioned=True)
+    eng = TrainEngine(tr, lr=1e-4, bf16_params=bf16)
+    dev_inputs = {k: v.to(device) for k, v in inputs.items()}
+    try:
+        eng.capture(dev_inputs, warmup=1, restore_state=True)
+        torch.manual_seed(5)
+        random.seed(5)
+        outputs, losses = eng.step(dev_inputs)
+        torch.cuda.synchronize()
+        grads = eng.named_grads()
+        tol_loss, tol_l2, tol_T, tol_cos = (3e-3, 2e-2, 1e-4, 2e-2) if bf16 else (1e-3, 1e-3, 1e-5, 1e-3)
+        bad = {}
+        for k, v in ref_losses.items():
+            e = rel_err(losses[k].detach().float().cpu(), v)
+            if e > tol_loss:
+                bad["loss:" + k] = e
+        for k, v in ref_out.items():
+            mine = outputs[k].detach().float().cpu()
+            e = float((mine.double() - v.double()).norm() / (v.double().norm() + 1e-30))
+            if e > (tol_T if k[0] == "cam_T_cam" else tol_l2):
+                bad["l2:" + str(k)] = e
+        for k, v in ref_grads.items():
+            a, b = grads[k].detach().double().cpu().reshape(-1), v.double().reshape(-1)
+            c = 1.0 - float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+            if c > tol_cos:
+                bad["grad_cos:" + k] = c
+            if not bf16 and abs(float(a.norm() / b.norm()) - 1.0) > 2e-2:
+                bad["grad_norm:" + k] = float(a.norm() / b.norm())
+        assert not bad, bad
+    finally:
+        rng.set_aug_buffer(None)
+        rng.set_mode("device")

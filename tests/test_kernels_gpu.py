@@ -711,6 +711,34 @@ def test_pose_matrix_kernel_equals_the_composite(device, invert):
     assert torch.isfinite(res[1][1]).all()
 
 
+@pytest.mark.parametrize("invert", [False, True])
+def test_pose_matrix_kernel_vs_reference_golden_and_oracle_autograd(device, golden, invert):
+    """A15 against the REFERENCE, not against this repo's own composite: (1) the kernel's matrices on
+    the golden's axis-angle / translation equal `layers_geometry.npz:T_fwd / T_inv` -- outputs of the reference's own
+    `transformation_from_parameters` (layers.py:26-58); (2) matrices and both input gradients equal the CPU oracle
+    (oracle/ref_ops.py, pinned to the same golden by tests/test_oracle_golden.py) under its autograd, on draws that cover
+    angles from 1e-3 to ~2 rad and a batch of 12."""
+    from oracle import ref_ops as R
+    from ppeadepth import layers
+    g = golden("layers_geometry")
+    aa, tt = g["axisangle"], g["translation"]
+    T = layers.transformation_from_parameters(aa.to(device), tt.to(device), invert)
+    assert rel_err(T.cpu(), g["T_inv" if invert else "T_fwd"]) < 2e-6
+    gen = _g(13 + int(invert))
+    aa = (torch.randn(12, 1, 3, generator=gen) * torch.tensor([1e-3, 1e-2, 0.1, 1.0] * 3).view(12, 1, 1))
+    tr = torch.randn(12, 1, 3, generator=gen)
+    go = torch.randn(12, 4, 4, generator=gen)
+    a0, t0 = aa.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+    T0 = R.transformation_from_parameters(a0, t0, invert)
+    (T0 * go).sum().backward()
+    a1, t1 = aa.clone().to(device).requires_grad_(True), tr.clone().to(device).requires_grad_(True)
+    assert layers.POSE_MATRIX_KERNEL
+    T1 = layers.transformation_from_parameters(a1, t1, invert)
+    (T1 * go.to(device)).sum().backward()
+    assert (T1.detach().cpu() - T0.detach()).abs().max() < 2e-6
+    assert rel_err(a1.grad.cpu(), a0.grad) < 1e-4 and rel_err(t1.grad.cpu(), t0.grad) < 1e-5
+
+
 def test_adam_flat_scaled_divides_rank_summed_gradients(device):
     """Several ranks: the exchange leaves the SUM of the gradients over the ranks in the flat buffer and the Adam kernel
     multiplies by 1 / world as it reads them -- bit-identical to a separate scaling pass followed by the plain kernel."""
