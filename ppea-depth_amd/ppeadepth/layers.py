@@ -93,7 +93,7 @@ class Conv3x3(nn.Module):
         super().__init__()
         self.use_refl = use_refl
         self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
-        self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
+        self.conv = ops.Conv2d(int(in_channels), int(out_channels), 3)
 
     def forward(self, x, act="none"):
         if self.use_refl and x.is_cuda:
@@ -122,7 +122,7 @@ class ConvBlock(nn.Module):
                 return y
         if FUSE_BIAS_ELU and x.is_cuda and c.use_refl and c.conv.bias is not None:
             # conv without bias, then bias + ELU in one pass whose backward also yields the bias gradient
-            z = F.conv2d(ops.reflect_pad1(x), c.conv.weight, None)
+            z = ops.conv2d(ops.reflect_pad1(x), c.conv.weight, None)
             if z.dtype in (torch.float32, torch.bfloat16):
                 return ops.bias_elu(z, c.conv.bias)
             return self.nonlin(z + c.conv.bias.view(1, -1, 1, 1))

@@ -91,6 +91,8 @@ class DepthDecoderV2(nn.Module):
                 a = self.adapter(torch.cat([input_features[0], x_up], 1))
             adpt_out = ops.conv_transpose_module(self.deconv_adpt, a)
             if adpt_out is None:
+                adpt_out = ops.conv_transpose_f32_module(self.deconv_adpt, a)        # fp32 step: csrc/conv_f32.hip
+            if adpt_out is None:
                 adpt_out = self.deconv_adpt(a)
         if NHWC and input_features[-1].is_cuda:
             # the decoder's 3x3 convolutions are implicit GEMMs over channels-last operands (csrc/conv_nhwc.hip): hand them

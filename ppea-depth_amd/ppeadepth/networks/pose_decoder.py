@@ -4,6 +4,8 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from .. import ops
+
 
 class PoseDecoder(nn.Module):
     def __init__(self, num_ch_enc, num_input_features, num_frames_to_predict_for=None, stride=1):
@@ -13,10 +15,10 @@ class PoseDecoder(nn.Module):
             num_frames_to_predict_for = num_input_features - 1
         self.num_frames_to_predict_for = num_frames_to_predict_for
         self.convs = OrderedDict()
-        self.convs["squeeze"] = nn.Conv2d(int(num_ch_enc[-1]), 256, 1)
-        self.convs[("pose", 0)] = nn.Conv2d(num_input_features * 256, 256, 3, stride, 1)
-        self.convs[("pose", 1)] = nn.Conv2d(256, 256, 3, stride, 1)
-        self.convs[("pose", 2)] = nn.Conv2d(256, 6 * num_frames_to_predict_for, 1)
+        self.convs["squeeze"] = ops.Conv2d(int(num_ch_enc[-1]), 256, 1)
+        self.convs[("pose", 0)] = ops.Conv2d(num_input_features * 256, 256, 3, stride, 1)
+        self.convs[("pose", 1)] = ops.Conv2d(256, 256, 3, stride, 1)
+        self.convs[("pose", 2)] = ops.Conv2d(256, 6 * num_frames_to_predict_for, 1)
         self.relu = nn.ReLU()
         self.net = nn.ModuleList(list(self.convs.values()))
 

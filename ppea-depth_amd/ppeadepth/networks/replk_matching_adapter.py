@@ -37,7 +37,7 @@ class RepLKMatchingAdapter(nn.Module):
         self.num_depth_bins = num_depth_bins
         self.depth_bins = None
         self.reduce_conv = nn.Sequential(
-            nn.Conv2d(int(self.num_ch_enc[0]) + num_depth_bins, int(self.num_ch_enc[0]), 3, 1, 1),
+            ops.Conv2d(int(self.num_ch_enc[0]) + num_depth_bins, int(self.num_ch_enc[0]), 3, 1, 1),
             nn.ReLU(inplace=True))
 
     # -- rkm.py:134-161 -------------------------------------------------------------------------

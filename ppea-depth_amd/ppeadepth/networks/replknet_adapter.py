@@ -141,7 +141,7 @@ class SmallDW(nn.Conv2d):
         return super().forward(x)
 
 
-class ImageConv(nn.Conv2d):
+class ImageConv(ops.Conv2d):
     """stem[0] (rka.py:411): dense 3x3 stride-2 conv on the RGB frame.  On the bf16 step: frame -> channels_last bf16
     padded to 8 channels, then this build's implicit-GEMM kernel writing NCHW for the trunk."""
 
@@ -150,7 +150,7 @@ class ImageConv(nn.Conv2d):
         return super().forward(x) if y is None else y
 
 
-class PointwiseConv(nn.Conv2d):
+class PointwiseConv(ops.Conv2d):
     """1x1 stride-1 conv; frozen + bf16 activations run on the NCHW MFMA kernel (forward with W, data
     gradient with W^T), everything else on the library conv."""
 
@@ -199,7 +199,8 @@ def get_conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation
         return LargeKernelDW(in_channels, k, bias=bias)
     if groups == 1 and k == 3 and in_channels < 8 and dilation == 1:
         return ImageConv(in_channels, out_channels, 3, stride, padding, dilation, 1, bias)
-    return nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+    cls = ops.Conv2d if groups == 1 else nn.Conv2d           # (dense: fp32 steps run on csrc/conv_f32.hip)
+    return cls(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
 
 
 class ConvBNAct(nn.Sequential):
@@ -242,6 +243,8 @@ def fuse_bn(conv, bn):
 def channel_linear(x, lin):
     """nn.Linear `lin` applied over the channel axis of x [B,C,H,W] -> [B,C_out,H,W]."""
     B, C, H, W = x.shape
+    if ops.conv2d_f32_ok(x, lin.weight):                    # fp32 step: a 1x1 convolution on the fp32 MFMA kernel
+        return ops.channel_linear_f32(x, lin.weight, lin.bias)
     w = lin.weight.unsqueeze(0).expand(B, -1, -1)          # stride-0 batch: one strided-batched GEMM, no copy
     xf = x.flatten(2)
     if lin.bias is not None:
@@ -282,11 +285,11 @@ class B_Adapter(nn.Module):
             self.D_fc1 = nn.Linear(D_features, hidden)
             self.D_fc2 = nn.Linear(hidden, D_features)
         elif adpt_test == 4:
-            self.D_fc1 = nn.Conv2d(D_features, hidden, 3, 1, 1)
+            self.D_fc1 = ops.Conv2d(D_features, hidden, 3, 1, 1)
             self.D_fc2 = nn.Linear(hidden, D_features)
         else:
-            self.D_fc1 = nn.Conv2d(D_features, hidden, 3, 1, 1)
-            self.D_fc2 = nn.Conv2d(hidden, D_features, 3, 1, 1)
+            self.D_fc1 = ops.Conv2d(D_features, hidden, 3, 1, 1)
+            self.D_fc2 = ops.Conv2d(hidden, D_features, 3, 1, 1)
 
     def forward(self, x):
         B, C, H, W = x.shape
@@ -294,7 +297,7 @@ class B_Adapter(nn.Module):
             fn = ops.conv_adapter if self.test_id == 4 else ops.mlp_adapter
             return fn(x, self.D_fc1.weight, self.D_fc1.bias, self.D_fc2.weight, self.D_fc2.bias)
         if self.test_id == 4:
-            if ADAPTER_CHANNELS_LAST and x.is_cuda:
+            if ADAPTER_CHANNELS_LAST and x.is_cuda and not ops.conv2d_f32_ok(x, self.D_fc1.weight):
                 # whole branch in NHWC: MIOpen's implicit-GEMM kernels are NHWC-native (no per-conv layout
                 # round trips), and Linear over channels is then a plain [B*HW, C/4] x [C/4, C] GEMM
                 xc = x.contiguous(memory_format=torch.channels_last)

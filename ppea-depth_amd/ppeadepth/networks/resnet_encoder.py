@@ -7,6 +7,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import ops
+
 
 CHANNELS_LAST = True
 FUSED_NHWC_BN = True      # pose-trunk BN + ReLU + residual on the channels_last HIP kernels (GroupBN.fused)
@@ -108,10 +110,10 @@ class BasicBlock(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.conv1 = ops.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
         self.bn1 = GroupBN(planes)
         self.relu = nn.ReLU(inplace=True)
-        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.conv2 = ops.Conv2d(planes, planes, 3, 1, 1, bias=False)
         self.bn2 = GroupBN(planes)
         self.downsample = downsample
         self.stride = stride
@@ -133,7 +135,7 @@ class ResNetMultiImageInput(nn.Module):
     def __init__(self, layers=(2, 2, 2, 2), num_classes=1000, num_input_images=1):
         super().__init__()
         self.inplanes = 64
-        self.conv1 = nn.Conv2d(num_input_images * 3, 64, 7, 2, 3, bias=False)
+        self.conv1 = ops.Conv2d(num_input_images * 3, 64, 7, 2, 3, bias=False)
         self.bn1 = GroupBN(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
@@ -153,7 +155,7 @@ class ResNetMultiImageInput(nn.Module):
     def _make_layer(self, planes, blocks, stride=1):
         down = None
         if stride != 1 or self.inplanes != planes:
-            down = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False), GroupBN(planes))
+            down = nn.Sequential(ops.Conv2d(self.inplanes, planes, 1, stride, bias=False), GroupBN(planes))
         layers = [BasicBlock(self.inplanes, planes, stride, down)]
         self.inplanes = planes
         layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]

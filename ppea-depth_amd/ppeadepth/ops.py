@@ -1548,6 +1548,154 @@ def pw_linear(x, w, b=None):
 
 
 # ---------------------------------------------------------------------------------------------
+# fp32 dense convolutions / linear layers on the fp32 matrix cores (csrc/conv_f32.hip): the fp32 (parity, BASELINE config 1)
+# step's replacement for the library convolution / GEMM behind every groups == 1 conv, nn.Linear and ConvTranspose2d of the
+# path (rka.py:20-109, 264-326; depth_decoder_v2.py:172-245; resnet_encoder.py:367-409; pose_decoder.py:27-52).  Operands
+# are addressed through element strides: NCHW and channels_last tensors go in as they are.
+# ---------------------------------------------------------------------------------------------
+CONV_F32_MFMA = True       # False: the library (tests compare the two)
+
+
+def _strides(t):
+    return (_ct.c_long * 4)(*[int(v) for v in t.stride()])
+
+
+def _like_format(x, shape):
+    cl = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+    return torch.empty(shape, device=x.device, dtype=_F32, memory_format=torch.channels_last if cl else torch.contiguous_format)
+
+
+def _f32_dense(x):
+    """A 4-D fp32 HIP tensor whose strides the kernels may use as they are (any dense or expanded layout)."""
+    return x if all(st >= 0 for st in x.stride()) else x.contiguous()
+
+
+class _Conv2dF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad):
+        x = _f32_dense(x)
+        N, Cin, H, W = x.shape
+        Cout, _, R, S = w.shape
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        wd = w.detach().contiguous()
+        y = _like_format(x, (N, Cout, Ho, Wo))
+        call("ppea_conv2d_f32_fwd", _raw(x), _strides(x), ptr(wd, _F32), None if bias is None else ptr(bias.detach().contiguous(), _F32),
+             _raw(y), _strides(y), N, Cin, H, W, Cout, R, S, stride, pad, stream_ptr())
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, Ho, Wo, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, Ho, Wo, has_bias = ctx.cfg
+        N, Cin, H, W = x.shape
+        Cout, _, R, S = w.shape
+        dy = _f32_dense(dy.float())
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _like_format(x, x.shape)
+            call("ppea_conv2d_f32_dgrad", _raw(dy), _strides(dy), ptr(w.detach().contiguous(), _F32), _raw(dx), _strides(dx),
+                 N, Cin, H, W, Cout, R, S, stride, pad, Ho, Wo, stream_ptr())
+        if ctx.needs_input_grad[1]:
+            nbytes = _abi.lib.ppea_conv2d_f32_wgrad_workspace_bytes(N, Cin, Cout, R, S, Ho, Wo)
+            ws = torch.empty(nbytes // 4, device=x.device, dtype=_F32) if nbytes else None
+            dw = torch.empty(Cout, Cin, R, S, device=x.device, dtype=_F32)
+            call("ppea_conv2d_f32_wgrad", _raw(x), _strides(x), _raw(dy), _strides(dy), ptr(dw), ptr(ws), N, Cin, H, W, Cout,
+                 R, S, stride, pad, Ho, Wo, stream_ptr())
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2, 3))
+        return dx, dw, db, None, None
+
+
+def conv2d_f32_ok(x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1, padding_mode="zeros"):
+    return (CONV_F32_MFMA and x.is_cuda and x.dim() == 4 and x.dtype == _F32 and w.dtype == _F32 and groups == 1
+            and tuple(dilation) == (1, 1) and not isinstance(padding, str) and padding_mode == "zeros"
+            and stride[0] == stride[1] and padding[0] == padding[1] and not torch.is_autocast_enabled())
+
+
+def conv2d_f32(x, w, bias=None, stride=1, pad=0):
+    """F.conv2d(x, w, bias, stride, pad) for fp32 HIP tensors, groups = 1, on the fp32 MFMA kernels."""
+    return _Conv2dF32.apply(x, w, bias, int(stride), int(pad))
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0):
+    """Dense conv of the path: fp32 HIP tensors on this build's kernel, anything else through torch."""
+    if conv2d_f32_ok(x, w, (stride, stride), (pad, pad)):
+        return conv2d_f32(x, w, bias, stride, pad)
+    return torch.nn.functional.conv2d(x, w, bias, stride, pad)
+
+
+class Conv2d(torch.nn.Conv2d):
+    """nn.Conv2d of this package: the bf16 step reaches the layout-specialised kernels through `conv_module` /
+    `pwconv_frozen`; whatever falls through to `nn.Conv2d.forward` lands HERE -- fp32 HIP tensors run on csrc/conv_f32.hip,
+    everything else (CPU tensors, eval-time dtypes) on torch's own convolution."""
+
+    def _conv_forward(self, input, weight, bias):
+        if conv2d_f32_ok(input, weight, self.stride, self.padding, self.dilation, self.groups, self.padding_mode):
+            return conv2d_f32(input, weight, bias, self.stride[0], self.padding[0])
+        return super()._conv_forward(input, weight, bias)
+
+
+def channel_linear_f32(x, w, b):
+    """nn.Linear(K -> M) over the channel axis of x [B,K,H,W] fp32 = a 1x1 convolution."""
+    return conv2d_f32(x, w.view(w.shape[0], w.shape[1], 1, 1), b, 1, 0)
+
+
+class _ConvTransposeF32(torch.autograd.Function):
+    """ConvTranspose2d (weight [Cin][Cout][R][S]) = the data gradient of the conv with that weight; its data gradient is that
+    conv's forward and its weight gradient that conv's weight gradient with the two activations exchanged."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, out_pad):
+        x = _f32_dense(x)
+        N, Cin, H, W = x.shape
+        _, Cout, R, S = w.shape
+        Ho, Wo = (H - 1) * stride - 2 * pad + R + out_pad, (W - 1) * stride - 2 * pad + S + out_pad
+        y = _like_format(x, (N, Cout, Ho, Wo))
+        call("ppea_conv2d_f32_dgrad", _raw(x), _strides(x), ptr(w.detach().contiguous(), _F32), _raw(y), _strides(y),
+             N, Cout, Ho, Wo, Cin, R, S, stride, pad, H, W, stream_ptr())
+        if bias is not None:
+            y += bias.detach().view(1, -1, 1, 1)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, Ho, Wo, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, Ho, Wo, has_bias = ctx.cfg
+        N, Cin, H, W = x.shape
+        _, Cout, R, S = w.shape
+        dy = _f32_dense(dy.float())
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _like_format(x, x.shape)
+            xs, ys = _strides(dy), _strides(dx)
+            call("ppea_conv2d_f32_fwd", _raw(dy), xs, ptr(w.detach().contiguous(), _F32), None, _raw(dx), ys, N, Cout, Ho, Wo,
+                 Cin, R, S, stride, pad, stream_ptr())
+        if ctx.needs_input_grad[1]:
+            nbytes = _abi.lib.ppea_conv2d_f32_wgrad_workspace_bytes(N, Cout, Cin, R, S, H, W)
+            ws = torch.empty(nbytes // 4, device=x.device, dtype=_F32) if nbytes else None
+            dw = torch.empty(Cin, Cout, R, S, device=x.device, dtype=_F32)
+            call("ppea_conv2d_f32_wgrad", _raw(dy), _strides(dy), _raw(x), _strides(x), ptr(dw), ptr(ws), N, Cout, Ho, Wo, Cin,
+                 R, S, stride, pad, H, W, stream_ptr())
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum((0, 2, 3))
+        return dx, dw, db, None, None, None
+
+
+def conv_transpose_f32_module(m, x):
+    """nn.ConvTranspose2d `m` on the fp32 MFMA kernels, or None when this call is not served."""
+    if not (CONV_F32_MFMA and x.is_cuda and x.dtype == _F32 and m.weight.dtype == _F32 and m.groups == 1
+            and tuple(m.dilation) == (1, 1) and m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1]
+            and m.output_padding[0] == m.output_padding[1] and m.kernel_size[0] == m.kernel_size[1]
+            and not torch.is_autocast_enabled()):
+        return None
+    return _ConvTransposeF32.apply(x, m.weight, m.bias, m.stride[0], m.padding[0], m.output_padding[0])
+
+
+# ---------------------------------------------------------------------------------------------
 # A13  transposed convolution of the Stage-2 decoder adapter (depth_decoder_v2.py:137-139: ConvTranspose2d(c, c, 3, 2, 1,
 # output_padding=1)) on the implicit-GEMM kernels: the forward IS the data gradient of a stride-2 conv, its data gradient is
 # that conv's forward, its weight gradient that conv's weight gradient with the two activations exchanged.

@@ -44,7 +44,9 @@ def _key(k):
 
 # how each golden was generated (oracle/gen_golden.py GENERATORS)
 CONFIG_OF = {"e2e_small_ckpt": dict(use_checkpoint=True), "e2e_l": dict(rep_size="l"),
-             "e2e_dc": dict(dc=True, intrinsics="cityscapes"), "e2e_render": dict(conditioned=True)}
+             "e2e_dc": dict(dc=True, intrinsics="cityscapes"), "e2e_render": dict(conditioned=True),
+             "e2e_render_l": dict(conditioned=True, rep_size="l"),
+             "e2e_render_dc": dict(conditioned=True, dc=True, intrinsics="cityscapes")}
 
 
 def _run(golden_name, golden, device, use_checkpoint=False, rep_size="b", dc=False, intrinsics="kitti", conditioned=False):
@@ -384,6 +386,40 @@ def test_bf16_step_launches_no_library_convolution_or_gemm(device, cfg):
     assert gemms <= 16, hits                                  # pose algebra only (13 per step at the time of writing)
     ours = sum(c for n, c in names.items() if "pwconv" in n or "conv_nhwc" in n or "dwconv_mfma" in n)
     assert ours > 200
+
+
+@pytest.mark.parametrize("cfg", ["b", "dc"])
+def test_fp32_step_launches_no_library_convolution_or_gemm(device, cfg):
+    """The fp32 (parity, BASELINE config 1) step is library-free too: its dense convolutions, linear
+    layers and the Stage-2 transposed conv run on csrc/conv_f32.hip (fp32 MFMA), so the 1e-3 end-to-end parity of
+    `test_e2e_*` / `test_engine_step_fp32_*` is earned on this build's kernels alone.  Same census as the bf16 test."""
+    import re
+    from torch.profiler import ProfilerActivity, profile
+    from ppeadepth import rng
+    from ppeadepth.dist import TrainEngine
+    B, H, W = 1, 64, 96
+    opt, model, tr = _build(device, B, H, W, use_checkpoint=True, dc=(cfg == "dc"), conditioned=True)
+    rng.set_mode("device")
+    eng = TrainEngine(tr, lr=1e-4)
+    inputs = {k: v.to(device) for k, v in synth.make_rendered_inputs(
+        B, H, W, intrinsics="cityscapes" if cfg == "dc" else "kitti").items()}
+    eng.step(dict(inputs))
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        _, losses = eng.step(dict(inputs))
+        torch.cuda.synchronize()
+    assert float(losses["loss"]) == float(losses["loss"])
+    names = {}
+    for ev in prof.events():
+        if str(ev.device_type).endswith("CUDA") and ev.name:
+            names[ev.name] = names.get(ev.name, 0) + 1
+    lib = re.compile(r"Cijk_|igemm|ck::|ck_tile|miopen|MIOpen|naive_conv|SubTensorOp|gemm_|Gemm|wmma|batched_transpose")
+    hits = {n: c for n, c in names.items() if lib.search(n)}
+    gemms = sum(c for n, c in hits.items() if "Cijk_" in n)
+    others = {n: c for n, c in hits.items() if "Cijk_" not in n}
+    assert not others, others
+    assert gemms <= 16, hits                                  # pose algebra only
+    assert sum(c for n, c in names.items() if "conv_f32" in n) > 300
 
 
 def test_stage2_step_at_512x1024_properties(device):

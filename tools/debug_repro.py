@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--B", type=int, default=2)
     ap.add_argument("--H", type=int, default=64)
     ap.add_argument("--W", type=int, default=96)
+    ap.add_argument("--alias-fork", action="store_true",
+                    help="after the default runs: the same step with the second-consumer alias handed to the FORKED adapters too "
+                         "(the topology DESIGN 5 recorded as a capture race), eager and replayed, against the default eager step")
     args = ap.parse_args()
     from ppeadepth import dist as pdist, networks, options, rng, synthetic as synth
     from ppeadepth.trainer import Trainer
@@ -95,6 +98,22 @@ def main():
         g2 = run("graph 2")
         compare(g1, g2, "graph vs graph")
         compare(g1, e1, "graph vs eager")
+    if args.alias_fork:
+        from ppeadepth.networks import replknet_adapter as rka
+        rka._DUP_FORK_DEBUG = True
+        eng.graph = None
+        f1 = run("alias+fork eager")
+        compare(f1, e1, "alias+fork eager vs default eager")
+        for i in range(3):
+            eng.graph = None
+            eng.restore(snap)
+            torch.manual_seed(3)
+            random.seed(3)
+            eng.capture(inputs, warmup=1, restore_state=True)
+            fg = run(f"alias+fork graph, capture {i}")
+            compare(fg, e1, f"alias+fork graph (capture {i}) vs default eager")
+            fg2 = run(f"alias+fork graph, capture {i}, second replay")
+            compare(fg2, e1, f"alias+fork graph (capture {i}, 2nd replay) vs default eager")
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

@@ -19,14 +19,16 @@ from conftest import load_golden  # noqa: E402
 def main():
     dev = torch.device("cuda:0")
     golden = load_golden
+    name = sys.argv[1] if len(sys.argv) > 1 else "e2e_render"          # e2e_render | e2e_render_l | e2e_render_dc
+    cfg = T.CONFIG_OF[name]
     cols = {}
-    cols["K/graph"] = T._errors(*T._engine_step("e2e_render", golden, dev, bf16=True, graph=True, conditioned=True))
-    cols["K/eager"] = T._errors(*T._engine_step("e2e_render", golden, dev, bf16=True, graph=False, conditioned=True))
+    cols["K/graph"] = T._errors(*T._engine_step(name, golden, dev, bf16=True, graph=True, **cfg))
+    cols["K/eager"] = T._errors(*T._engine_step(name, golden, dev, bf16=True, graph=False, **cfg))
     with T._plain_torch_bf16():
-        cols["torch"] = T._errors(*T._engine_step("e2e_render", golden, dev, bf16=True, graph=False, conditioned=True))
-    cols["fp32"] = T._errors(*T._engine_step("e2e_render", golden, dev, bf16=False, graph=True, conditioned=True))
+        cols["torch"] = T._errors(*T._engine_step(name, golden, dev, bf16=True, graph=False, **cfg))
+    cols["fp32"] = T._errors(*T._engine_step(name, golden, dev, bf16=False, graph=True, **cfg))
     names = list(cols)
-    print("bf16 training step vs the reference's fp32 golden on the well-conditioned rendered fixture (e2e_render)")
+    print(f"bf16 training step vs the reference's fp32 golden on the well-conditioned rendered fixture ({name})")
     print("K = this build's bf16 kernels (graph replay / eager), torch = plain torch bf16 autocast, fp32 = this build in fp32")
     print("%-66s" % "" + "".join("%11s" % n for n in names))
     for k in sorted(cols[names[0]]):
