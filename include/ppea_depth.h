@@ -461,6 +461,16 @@ int ppea_conv2d_f32_dgrad(const float* dy, const long* dys, const float* w, floa
 long ppea_conv2d_f32_wgrad_workspace_bytes(int N, int Cin, int Cout, int R, int S, int Ho, int Wo);
 int ppea_conv2d_f32_wgrad(const float* x, const long* xs, const float* dy, const long* dys, float* dw, float* workspace, int N,
                           int Cin, int H, int W, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, void* stream);
+/* The same family for bf16 weights / activations / results (widened as they are staged, fp32 products and sums on the same
+ * instruction, one rounding at the store; bias and dw stay fp32): what the bf16 step uses for shapes the layout-specialised
+ * bf16 kernels do not take (map widths that are not a multiple of 4 pixels, channel counts that are not multiples of
+ * 8 / 32: reduced-size test configurations), so that no shape of either dtype reaches a library convolution or GEMM. */
+int ppea_conv2d_bf16_fwd(const void* x, const long* xs, const void* w, const float* bias, void* y, const long* ys, int N,
+                         int Cin, int H, int W, int Cout, int R, int S, int stride, int pad, void* stream);
+int ppea_conv2d_bf16_dgrad(const void* dy, const long* dys, const void* w, void* dx, const long* dxs, int N, int Cin, int H,
+                           int W, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, void* stream);
+int ppea_conv2d_bf16_wgrad(const void* x, const long* xs, const void* dy, const long* dys, float* dw, float* workspace, int N,
+                           int Cin, int H, int W, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, void* stream);
 
 /* Image-fed convolutions (csrc/conv_image.hip): RepLKNet stem[0] (networks/replknet_adapter.py:411, 3x3 stride 2) and
  * the pose ResNet-18 conv1 (networks/resnet_encoder.py:376-388, 7x7 stride 2).  The frame is channels-last bf16 with its

@@ -29,10 +29,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TM = 64, TN = 64, KC = 16, PITCH = TN + 4, TPB = 256;
 
 struct CvArgs {
-    const float* a;        // weights (fwd / dgrad) or dy (wgrad)
-    const float* b;        // x (fwd, wgrad) or dy (dgrad)
-    const float* bias;
-    float* y;
+    const void* a;         // weights (fwd / dgrad) or dy (wgrad): float, or bf16 in the T = uint16_t instantiation
+    const void* b;         // x (fwd, wgrad) or dy (dgrad)
+    const float* bias;     // always fp32
+    void* y;               // T (wgrad: fp32 slabs)
     long bs[4];            // element strides (n, c, h, w) of the gathered operand
     long as[4];            // wgrad: element strides of dy
     long ys[4];            // element strides of the result (fwd: y, dgrad: dx)
@@ -52,9 +52,13 @@ __device__ __forceinline__ void mfma_chunk(const float (*As)[PITCH], const float
     }
 }
 
-// MODE 0: forward, 1: data gradient
-template <int MODE>
+// MODE 0: forward, 1: data gradient.  T: element type of weights, activations and result (float, or uint16_t = bf16: the
+// operands are widened as they are staged, products and sums stay fp32, the result is rounded once).
+template <int MODE, typename T>
 __global__ __launch_bounds__(TPB) void conv_f32_kernel(CvArgs p) {
+    const T* pa = (const T*)p.a;
+    const T* pb = (const T*)p.b;
+    T* py_out = (T*)p.y;
     __shared__ float As[KC][PITCH];
     __shared__ float Bs[KC][PITCH];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(TPB) void conv_f32_kernel(CvArgs p) {
                 const int m = m0 + am + 16 * i;
                 float v = 0.f;
                 if (m < p.M && k < p.K)
-                    v = MODE == 0 ? p.a[(long)m * p.K + k] : p.a[(((long)c2 * p.Cin + m) * p.R + r) * p.S + s];
+                    v = ld_f32<T>(MODE == 0 ? pa + ((long)m * p.K + k) : pa + ((((long)c2 * p.Cin + m) * p.R + r) * p.S + s));
                 As[akk][am + 16 * i] = v;
             }
         }
@@ -109,13 +113,13 @@ __global__ __launch_bounds__(TPB) void conv_f32_kernel(CvArgs p) {
                 if (MODE == 0) {
                     const int iy = py * p.stride - p.pad + r, ix = px * p.stride - p.pad + s;
                     if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                        v = p.b[pn * p.bs[0] + c2 * p.bs[1] + iy * p.bs[2] + ix * p.bs[3]];
+                        v = ld_f32<T>(pb + (pn * p.bs[0] + c2 * p.bs[1] + iy * p.bs[2] + ix * p.bs[3]));
                 } else {
                     const int ty = py + p.pad - r, tx = px + p.pad - s;
                     if (ty >= 0 && tx >= 0) {
                         const int oy = ty / p.stride, ox = tx / p.stride;
                         if (oy * p.stride == ty && ox * p.stride == tx && oy < p.Ho && ox < p.Wo)
-                            v = p.b[pn * p.bs[0] + c2 * p.bs[1] + oy * p.bs[2] + ox * p.bs[3]];
+                            v = ld_f32<T>(pb + (pn * p.bs[0] + c2 * p.bs[1] + oy * p.bs[2] + ox * p.bs[3]));
                     }
                 }
             }
@@ -135,13 +139,16 @@ __global__ __launch_bounds__(TPB) void conv_f32_kernel(CvArgs p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int m = m0 + wm * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
-            if (m < p.M) p.y[base + m * p.ys[1]] = acc[i] + (p.bias != nullptr ? p.bias[m] : 0.f);
+            if (m < p.M) st_f32<T>(py_out + (base + m * p.ys[1]), acc[i] + (p.bias != nullptr ? p.bias[m] : 0.f));
         }
     }
 }
 
-// weight gradient: rows = output channels, columns = (ci, r, s), contraction = pixels [z kper, (z + 1) kper)
+// weight gradient: rows = output channels, columns = (ci, r, s), contraction = pixels [z kper, (z + 1) kper); fp32 slabs
+template <typename T>
 __global__ __launch_bounds__(TPB) void conv_f32_wgrad_kernel(CvArgs p) {
+    const T* pa = (const T*)p.a;
+    const T* pb = (const T*)p.b;
     __shared__ float As[KC][PITCH];
     __shared__ float Bs[KC][PITCH];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(TPB) void conv_f32_wgrad_kernel(CvArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + am + 16 * i;
-                As[akk][am + 16 * i] = (kok && m < p.M) ? p.a[off + m * p.as[1]] : 0.f;
+                As[akk][am + 16 * i] = (kok && m < p.M) ? ld_f32<T>(pa + (off + m * p.as[1])) : 0.f;
             }
         }
 #pragma unroll
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(TPB) void conv_f32_wgrad_kernel(CvArgs p) {
                 const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
                 const int iy = oy * p.stride - p.pad + jr, ix = ox * p.stride - p.pad + js;
                 if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                    v = p.b[n * p.bs[0] + jc * p.bs[1] + iy * p.bs[2] + ix * p.bs[3]];
+                    v = ld_f32<T>(pb + (n * p.bs[0] + jc * p.bs[1] + iy * p.bs[2] + ix * p.bs[3]));
             }
             Bs[kk][t & 63] = v;
         }
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(TPB) void conv_f32_wgrad_kernel(CvArgs p) {
         mfma_chunk(As, Bs, wm, wn, lane, acc);
         __syncthreads();
     }
-    float* out = p.y + (long)blockIdx.z * p.M * p.NC;
+    float* out = (float*)p.y + (long)blockIdx.z * p.M * p.NC;
     const int col = n0 + wn * 32 + (lane & 31);
     if (col < p.NC) {
 #pragma unroll
@@ -229,14 +236,9 @@ int wgrad_splits(int M, int NC, long K) {
 
 bool fits_int(long v) { return v > 0 && v < (1L << 31); }
 
-}  // namespace
-
-extern "C" {
-
-// xs / ys: four element strides (n, c, h, w) of x / y (NCHW, channels_last, or a [tokens][features] matrix viewed as
-// [1][features][tokens][1]); w: [Cout][Cin][R][S] contiguous; bias: [Cout] or NULL.
-int ppea_conv2d_f32_fwd(const float* x, const long* xs, const float* w, const float* bias, float* y, const long* ys, int N,
-                        int Cin, int H, int W, int Cout, int R, int S, int stride, int pad, void* stream) {
+template <typename T>
+int fwd_impl(const void* x, const long* xs, const void* w, const float* bias, void* y, const long* ys, int N, int Cin, int H,
+             int W, int Cout, int R, int S, int stride, int pad, void* stream) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return PPEA_ERR_ARG;
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     if (Ho <= 0 || Wo <= 0 || !fits_int((long)N * Ho * Wo) || !fits_int((long)Cin * R * S)) return PPEA_ERR_UNSUPPORTED;
@@ -247,13 +249,13 @@ int ppea_conv2d_f32_fwd(const float* x, const long* xs, const float* w, const fl
     p.M = Cout; p.NC = N * Ho * Wo; p.K = Cin * R * S;
     dim3 grid((p.NC + TN - 1) / TN, (p.M + TM - 1) / TM);
     if (grid.y > 65535) return PPEA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(conv_f32_kernel<0>, grid, dim3(TPB), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((conv_f32_kernel<0, T>), grid, dim3(TPB), 0, (hipStream_t)stream, p);
     return launch_status();
 }
 
-// dx [N][Cin][H][W] (strides dxs) from dy [N][Cout][Ho][Wo] (strides dys): every element of dx is written.
-int ppea_conv2d_f32_dgrad(const float* dy, const long* dys, const float* w, float* dx, const long* dxs, int N, int Cin, int H,
-                          int W, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, void* stream) {
+template <typename T>
+int dgrad_impl(const void* dy, const long* dys, const void* w, void* dx, const long* dxs, int N, int Cin, int H, int W, int Cout,
+               int R, int S, int stride, int pad, int Ho, int Wo, void* stream) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0 || Ho <= 0 || Wo <= 0) return PPEA_ERR_ARG;
     if (!fits_int((long)N * H * W) || !fits_int((long)Cout * R * S)) return PPEA_ERR_UNSUPPORTED;
     CvArgs p{};
@@ -263,18 +265,13 @@ int ppea_conv2d_f32_dgrad(const float* dy, const long* dys, const float* w, floa
     p.M = Cin; p.NC = N * H * W; p.K = Cout * R * S;
     dim3 grid((p.NC + TN - 1) / TN, (p.M + TM - 1) / TM);
     if (grid.y > 65535) return PPEA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(conv_f32_kernel<1>, grid, dim3(TPB), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((conv_f32_kernel<1, T>), grid, dim3(TPB), 0, (hipStream_t)stream, p);
     return launch_status();
 }
 
-long ppea_conv2d_f32_wgrad_workspace_bytes(int N, int Cin, int Cout, int R, int S, int Ho, int Wo) {
-    const int splits = wgrad_splits(Cout, Cin * R * S, (long)N * Ho * Wo);
-    return splits > 1 ? (long)splits * Cout * Cin * R * S * 4 : 0;
-}
-
-// dw [Cout][Cin][R][S] contiguous; workspace: ppea_conv2d_f32_wgrad_workspace_bytes(...) bytes (may be NULL when that is 0).
-int ppea_conv2d_f32_wgrad(const float* x, const long* xs, const float* dy, const long* dys, float* dw, float* workspace, int N,
-                          int Cin, int H, int W, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, void* stream) {
+template <typename T>
+int wgrad_impl(const void* x, const long* xs, const void* dy, const long* dys, float* dw, float* workspace, int N, int Cin, int H,
+               int W, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, void* stream) {
     if (N <= 0 || Cin <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0 || Ho <= 0 || Wo <= 0) return PPEA_ERR_ARG;
     if (!fits_int((long)N * Ho * Wo) || !fits_int((long)Cin * R * S)) return PPEA_ERR_UNSUPPORTED;
     CvArgs p{};
@@ -288,13 +285,54 @@ int ppea_conv2d_f32_wgrad(const float* x, const long* xs, const float* dy, const
     p.y = splits > 1 ? workspace : dw;
     dim3 grid((p.NC + TN - 1) / TN, (p.M + TM - 1) / TM, splits);
     if (grid.y > 65535) return PPEA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(conv_f32_wgrad_kernel, grid, dim3(TPB), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((conv_f32_wgrad_kernel<T>), grid, dim3(TPB), 0, (hipStream_t)stream, p);
     if (splits > 1) {
         const long n = (long)p.M * p.NC;
         hipLaunchKernelGGL(conv_f32_slab_sum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace,
                            dw, n, splits);
     }
     return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+// xs / ys: four element strides (n, c, h, w) of x / y (NCHW, channels_last, or a [tokens][features] matrix viewed as
+// [1][features][tokens][1]); w: [Cout][Cin][R][S] contiguous; bias: fp32 [Cout] or NULL.
+int ppea_conv2d_f32_fwd(const float* x, const long* xs, const float* w, const float* bias, float* y, const long* ys, int N,
+                        int Cin, int H, int W, int Cout, int R, int S, int stride, int pad, void* stream) {
+    return fwd_impl<float>(x, xs, w, bias, y, ys, N, Cin, H, W, Cout, R, S, stride, pad, stream);
+}
+// dx [N][Cin][H][W] (strides dxs) from dy [N][Cout][Ho][Wo] (strides dys): every element of dx is written.
+int ppea_conv2d_f32_dgrad(const float* dy, const long* dys, const float* w, float* dx, const long* dxs, int N, int Cin, int H,
+                          int W, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, void* stream) {
+    return dgrad_impl<float>(dy, dys, w, dx, dxs, N, Cin, H, W, Cout, R, S, stride, pad, Ho, Wo, stream);
+}
+long ppea_conv2d_f32_wgrad_workspace_bytes(int N, int Cin, int Cout, int R, int S, int Ho, int Wo) {
+    const int splits = wgrad_splits(Cout, Cin * R * S, (long)N * Ho * Wo);
+    return splits > 1 ? (long)splits * Cout * Cin * R * S * 4 : 0;
+}
+// dw [Cout][Cin][R][S] contiguous fp32; workspace: ppea_conv2d_f32_wgrad_workspace_bytes(...) bytes (NULL when that is 0).
+int ppea_conv2d_f32_wgrad(const float* x, const long* xs, const float* dy, const long* dys, float* dw, float* workspace, int N,
+                          int Cin, int H, int W, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, void* stream) {
+    return wgrad_impl<float>(x, xs, dy, dys, dw, workspace, N, Cin, H, W, Cout, R, S, stride, pad, Ho, Wo, stream);
+}
+// The same family for bf16 weights / activations / results (fp32 products and sums on the same fp32 matrix-core
+// instruction, one rounding at the store; dw stays fp32): what the bf16 step falls back to for shapes the layout-specialised
+// bf16 kernels do not take (maps whose width is not a multiple of 4 pixels, channel counts that are not multiples of 8 /
+// 32 -- reduced-size test configurations), so that no shape of either dtype reaches a library convolution.
+int ppea_conv2d_bf16_fwd(const void* x, const long* xs, const void* w, const float* bias, void* y, const long* ys, int N,
+                         int Cin, int H, int W, int Cout, int R, int S, int stride, int pad, void* stream) {
+    return fwd_impl<uint16_t>(x, xs, w, bias, y, ys, N, Cin, H, W, Cout, R, S, stride, pad, stream);
+}
+int ppea_conv2d_bf16_dgrad(const void* dy, const long* dys, const void* w, void* dx, const long* dxs, int N, int Cin, int H,
+                           int W, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, void* stream) {
+    return dgrad_impl<uint16_t>(dy, dys, w, dx, dxs, N, Cin, H, W, Cout, R, S, stride, pad, Ho, Wo, stream);
+}
+int ppea_conv2d_bf16_wgrad(const void* x, const long* xs, const void* dy, const long* dys, float* dw, float* workspace, int N,
+                           int Cin, int H, int W, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, void* stream) {
+    return wgrad_impl<uint16_t>(x, xs, dy, dys, dw, workspace, N, Cin, H, W, Cout, R, S, stride, pad, Ho, Wo, stream);
 }
 
 }  // extern "C"

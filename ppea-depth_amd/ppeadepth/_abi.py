@@ -152,6 +152,9 @@ SIGNATURES = {
     "ppea_conv2d_f32_dgrad": [_vp] * 5 + [_i] * 11 + [_vp],
     "ppea_conv2d_f32_wgrad_workspace_bytes": [_i] * 7,
     "ppea_conv2d_f32_wgrad": [_vp] * 6 + [_i] * 11 + [_vp],
+    "ppea_conv2d_bf16_fwd": [_vp] * 6 + [_i] * 9 + [_vp],
+    "ppea_conv2d_bf16_dgrad": [_vp] * 5 + [_i] * 11 + [_vp],
+    "ppea_conv2d_bf16_wgrad": [_vp] * 6 + [_i] * 11 + [_vp],
     "ppea_cost_volume_fwd_f32": [_vp] * 7 + [_i] * 5 + [_f, _vp],
     "ppea_cost_volume_reduce_f32": [_vp] * 6 + [_i] * 4 + [_vp],
 }

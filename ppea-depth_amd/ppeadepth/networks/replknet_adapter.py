@@ -35,7 +35,14 @@ def get_bn(channels):
 
 ADAPTER_STREAMS = os.environ.get("PPEA_ADAPTER_STREAMS", "1") == "1"   # adapters of the student on a forked side stream
 _SIDE = {}
-_DUP_FORK_DEBUG = False      # set by tools/graph_edges_dup.py ONLY: the alias for forked adapters too
+# The second-consumer alias of a block's first BatchNorm output (batchnorm.second_use) is handed to the FORKED adapters too
+# (round 4).  Round 3 recorded "wrong encoder gradients in 2 of 3 captures" for this topology and parked it; the cause was
+# not a capture race: tools/graph_edges_dup.py reads the captured hipGraph back (every kernel that touches the alias
+# gradient's buffer is ordered with the launch that consumes it), and tools/debug_repro.py shows that with the library
+# convolutions gone (fp32: csrc/conv_f32.hip) the step is a pure function of (state, inputs, seeds) -- eager, replayed,
+# with or without the alias: 0 of 4 220 tensors differ.  What differed in round 3 were MIOpen's fp32 igemm kernels
+# (atomic accumulation: different bits on every run), amplified by the chaotic random-weight fixture.  DESIGN 5.
+BN_DUP_FORKED = os.environ.get("PPEA_BN_DUP_FORK", "1") == "1"
 NO_FORK_ON = set()       # cuda_stream handles on which adapters run inline (already a forked branch)
 
 
@@ -413,12 +420,10 @@ class ConvFFN(nn.Module):
             adpt, join = None, None
             if self.test_id >= 0:
                 if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
-                    adpt, join = _forked_adapter(self.mlp_adapter, second_use(out) if _DUP_FORK_DEBUG else out)
+                    adpt, join = _forked_adapter(self.mlp_adapter, second_use(out) if BN_DUP_FORKED else out)
                 else:
-                    # in line: hand the adapter the alias of `out` whose gradient joins pw1's inside the BatchNorm's backward
-                    # launch (batchnorm.second_use).  NOT for the forked adapter: with the alias's gradient produced on the side
-                    # stream, replayed hipGraphs of the fp32 step gave wrong encoder gradients in 2 of 3 captures (eager steps
-                    # and the in-line form never did; cause not found)
+                    # hand the adapter the alias of `out` whose gradient joins pw1's inside the BatchNorm's backward launch
+                    # (batchnorm.second_use)
                     adpt = self.mlp_adapter(second_use(out))
             # (the BatchNorm + GELU over the 4C-wide hidden tensor takes its statistics from the GEMM's epilogue at every size)
             z1, s1 = _conv_sums(self.pw1.conv, out, BN_SUMS_FFN)
@@ -498,7 +503,7 @@ class RepLKBlock(nn.Module):
             adpt, join = None, None
             if self.test_id >= 0:
                 if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
-                    adpt, join = _forked_adapter(self.adapter, second_use(out) if _DUP_FORK_DEBUG else out)
+                    adpt, join = _forked_adapter(self.adapter, second_use(out) if BN_DUP_FORKED else out)
                 else:
                     adpt = self.adapter(second_use(out))         # (see ConvFFN.forward)
             t = self._pw1_large_kernel_fused(out)

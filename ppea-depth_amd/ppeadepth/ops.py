@@ -1570,57 +1570,80 @@ def _f32_dense(x):
     return x if all(st >= 0 for st in x.stride()) else x.contiguous()
 
 
+def _gen_sfx(x):
+    return "bf16" if x.dtype == _BF16 else "f32"
+
+
+def _gen_out(x, shape):
+    cl = x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+    return torch.empty(shape, device=x.device, dtype=x.dtype, memory_format=torch.channels_last if cl else torch.contiguous_format)
+
+
+def _f32_vec(b):
+    return None if b is None else ptr(b.detach().float().contiguous(), _F32)
+
+
 class _Conv2dF32(torch.autograd.Function):
+    """x, w both fp32 or both bf16 (the caller casts); bias any float dtype (read as fp32)."""
+
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad):
         x = _f32_dense(x)
         N, Cin, H, W = x.shape
         Cout, _, R, S = w.shape
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
-        wd = w.detach().contiguous()
-        y = _like_format(x, (N, Cout, Ho, Wo))
-        call("ppea_conv2d_f32_fwd", _raw(x), _strides(x), ptr(wd, _F32), None if bias is None else ptr(bias.detach().contiguous(), _F32),
-             _raw(y), _strides(y), N, Cin, H, W, Cout, R, S, stride, pad, stream_ptr())
-        ctx.save_for_backward(x, w)
-        ctx.cfg = (stride, pad, Ho, Wo, bias is not None)
+        wd = w.detach().to(x.dtype).contiguous()
+        y = _gen_out(x, (N, Cout, Ho, Wo))
+        call(f"ppea_conv2d_{_gen_sfx(x)}_fwd", _raw(x), _strides(x), ptr(wd), _f32_vec(bias), _raw(y), _strides(y), N, Cin, H, W,
+             Cout, R, S, stride, pad, stream_ptr())
+        ctx.save_for_backward(x, wd)
+        ctx.cfg = (stride, pad, Ho, Wo, None if bias is None else bias.dtype, w.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        stride, pad, Ho, Wo, has_bias = ctx.cfg
+        x, wd = ctx.saved_tensors
+        stride, pad, Ho, Wo, bdt, wdt = ctx.cfg
         N, Cin, H, W = x.shape
-        Cout, _, R, S = w.shape
-        dy = _f32_dense(dy.float())
+        Cout, _, R, S = wd.shape
+        dy = _f32_dense(dy.to(x.dtype))
+        sfx = _gen_sfx(x)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _like_format(x, x.shape)
-            call("ppea_conv2d_f32_dgrad", _raw(dy), _strides(dy), ptr(w.detach().contiguous(), _F32), _raw(dx), _strides(dx),
-                 N, Cin, H, W, Cout, R, S, stride, pad, Ho, Wo, stream_ptr())
+            dx = _gen_out(x, x.shape)
+            call(f"ppea_conv2d_{sfx}_dgrad", _raw(dy), _strides(dy), ptr(wd), _raw(dx), _strides(dx), N, Cin, H, W, Cout, R, S,
+                 stride, pad, Ho, Wo, stream_ptr())
         if ctx.needs_input_grad[1]:
             nbytes = _abi.lib.ppea_conv2d_f32_wgrad_workspace_bytes(N, Cin, Cout, R, S, Ho, Wo)
             ws = torch.empty(nbytes // 4, device=x.device, dtype=_F32) if nbytes else None
             dw = torch.empty(Cout, Cin, R, S, device=x.device, dtype=_F32)
-            call("ppea_conv2d_f32_wgrad", _raw(x), _strides(x), _raw(dy), _strides(dy), ptr(dw), ptr(ws), N, Cin, H, W, Cout,
+            call(f"ppea_conv2d_{sfx}_wgrad", _raw(x), _strides(x), _raw(dy), _strides(dy), ptr(dw), ptr(ws), N, Cin, H, W, Cout,
                  R, S, stride, pad, Ho, Wo, stream_ptr())
-        if has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 2, 3))
+            dw = dw.to(wdt)
+        if bdt is not None and ctx.needs_input_grad[2]:
+            db = dy.float().sum((0, 2, 3)).to(bdt)
         return dx, dw, db, None, None
 
 
 def conv2d_f32_ok(x, w, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1, padding_mode="zeros"):
-    return (CONV_F32_MFMA and x.is_cuda and x.dim() == 4 and x.dtype == _F32 and w.dtype == _F32 and groups == 1
-            and tuple(dilation) == (1, 1) and not isinstance(padding, str) and padding_mode == "zeros"
-            and stride[0] == stride[1] and padding[0] == padding[1] and not torch.is_autocast_enabled())
+    """This call is served by csrc/conv_f32.hip: fp32 tensors outside autocast (the fp32 step), or bf16 activations (the bf16
+    step's shapes that its layout-specialised kernels do not take)."""
+    if not (CONV_F32_MFMA and x.is_cuda and x.dim() == 4 and groups == 1 and tuple(dilation) == (1, 1)
+            and not isinstance(padding, str) and padding_mode == "zeros" and stride[0] == stride[1]
+            and padding[0] == padding[1] and w.dtype in (_F32, _BF16)):
+        return False
+    if x.dtype == _BF16:
+        return True
+    return x.dtype == _F32 and w.dtype == _F32 and not torch.is_autocast_enabled()
 
 
 def conv2d_f32(x, w, bias=None, stride=1, pad=0):
-    """F.conv2d(x, w, bias, stride, pad) for fp32 HIP tensors, groups = 1, on the fp32 MFMA kernels."""
+    """F.conv2d(x, w, bias, stride, pad), groups = 1, on the fp32 MFMA kernels (fp32, or bf16 storage with fp32 arithmetic)."""
     return _Conv2dF32.apply(x, w, bias, int(stride), int(pad))
 
 
 def conv2d(x, w, bias=None, stride=1, pad=0):
-    """Dense conv of the path: fp32 HIP tensors on this build's kernel, anything else through torch."""
+    """Dense conv of the path: HIP tensors on this build's kernel, anything else through torch."""
     if conv2d_f32_ok(x, w, (stride, stride), (pad, pad)):
         return conv2d_f32(x, w, bias, stride, pad)
     return torch.nn.functional.conv2d(x, w, bias, stride, pad)
@@ -1628,8 +1651,8 @@ def conv2d(x, w, bias=None, stride=1, pad=0):
 
 class Conv2d(torch.nn.Conv2d):
     """nn.Conv2d of this package: the bf16 step reaches the layout-specialised kernels through `conv_module` /
-    `pwconv_frozen`; whatever falls through to `nn.Conv2d.forward` lands HERE -- fp32 HIP tensors run on csrc/conv_f32.hip,
-    everything else (CPU tensors, eval-time dtypes) on torch's own convolution."""
+    `pwconv_frozen`; whatever falls through to `nn.Conv2d.forward` lands HERE -- HIP tensors run on csrc/conv_f32.hip (fp32
+    step: every dense conv; bf16 step: shapes the specialised kernels refuse), everything else (CPU tensors) on torch."""
 
     def _conv_forward(self, input, weight, bias):
         if conv2d_f32_ok(input, weight, self.stride, self.padding, self.dilation, self.groups, self.padding_mode):
@@ -1638,7 +1661,7 @@ class Conv2d(torch.nn.Conv2d):
 
 
 def channel_linear_f32(x, w, b):
-    """nn.Linear(K -> M) over the channel axis of x [B,K,H,W] fp32 = a 1x1 convolution."""
+    """nn.Linear(K -> M) over the channel axis of x [B,K,H,W] = a 1x1 convolution."""
     return conv2d_f32(x, w.view(w.shape[0], w.shape[1], 1, 1), b, 1, 0)
 
 
@@ -1652,45 +1675,47 @@ class _ConvTransposeF32(torch.autograd.Function):
         N, Cin, H, W = x.shape
         _, Cout, R, S = w.shape
         Ho, Wo = (H - 1) * stride - 2 * pad + R + out_pad, (W - 1) * stride - 2 * pad + S + out_pad
-        y = _like_format(x, (N, Cout, Ho, Wo))
-        call("ppea_conv2d_f32_dgrad", _raw(x), _strides(x), ptr(w.detach().contiguous(), _F32), _raw(y), _strides(y),
-             N, Cout, Ho, Wo, Cin, R, S, stride, pad, H, W, stream_ptr())
+        wd = w.detach().to(x.dtype).contiguous()
+        y = _gen_out(x, (N, Cout, Ho, Wo))
+        call(f"ppea_conv2d_{_gen_sfx(x)}_dgrad", _raw(x), _strides(x), ptr(wd), _raw(y), _strides(y), N, Cout, Ho, Wo, Cin, R, S,
+             stride, pad, H, W, stream_ptr())
         if bias is not None:
-            y += bias.detach().view(1, -1, 1, 1)
-        ctx.save_for_backward(x, w)
-        ctx.cfg = (stride, pad, Ho, Wo, bias is not None)
+            y += bias.detach().to(y.dtype).view(1, -1, 1, 1)
+        ctx.save_for_backward(x, wd)
+        ctx.cfg = (stride, pad, Ho, Wo, None if bias is None else bias.dtype, w.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        stride, pad, Ho, Wo, has_bias = ctx.cfg
+        x, wd = ctx.saved_tensors
+        stride, pad, Ho, Wo, bdt, wdt = ctx.cfg
         N, Cin, H, W = x.shape
-        _, Cout, R, S = w.shape
-        dy = _f32_dense(dy.float())
+        _, Cout, R, S = wd.shape
+        dy = _f32_dense(dy.to(x.dtype))
+        sfx = _gen_sfx(x)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _like_format(x, x.shape)
-            xs, ys = _strides(dy), _strides(dx)
-            call("ppea_conv2d_f32_fwd", _raw(dy), xs, ptr(w.detach().contiguous(), _F32), None, _raw(dx), ys, N, Cout, Ho, Wo,
-                 Cin, R, S, stride, pad, stream_ptr())
+            dx = _gen_out(x, x.shape)
+            call(f"ppea_conv2d_{sfx}_fwd", _raw(dy), _strides(dy), ptr(wd), None, _raw(dx), _strides(dx), N, Cout, Ho, Wo, Cin, R, S,
+                 stride, pad, stream_ptr())
         if ctx.needs_input_grad[1]:
             nbytes = _abi.lib.ppea_conv2d_f32_wgrad_workspace_bytes(N, Cout, Cin, R, S, H, W)
             ws = torch.empty(nbytes // 4, device=x.device, dtype=_F32) if nbytes else None
             dw = torch.empty(Cin, Cout, R, S, device=x.device, dtype=_F32)
-            call("ppea_conv2d_f32_wgrad", _raw(dy), _strides(dy), _raw(x), _strides(x), ptr(dw), ptr(ws), N, Cout, Ho, Wo, Cin,
+            call(f"ppea_conv2d_{sfx}_wgrad", _raw(dy), _strides(dy), _raw(x), _strides(x), ptr(dw), ptr(ws), N, Cout, Ho, Wo, Cin,
                  R, S, stride, pad, H, W, stream_ptr())
-        if has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum((0, 2, 3))
+            dw = dw.to(wdt)
+        if bdt is not None and ctx.needs_input_grad[2]:
+            db = dy.float().sum((0, 2, 3)).to(bdt)
         return dx, dw, db, None, None, None
 
 
 def conv_transpose_f32_module(m, x):
     """nn.ConvTranspose2d `m` on the fp32 MFMA kernels, or None when this call is not served."""
-    if not (CONV_F32_MFMA and x.is_cuda and x.dtype == _F32 and m.weight.dtype == _F32 and m.groups == 1
-            and tuple(m.dilation) == (1, 1) and m.stride[0] == m.stride[1] and m.padding[0] == m.padding[1]
-            and m.output_padding[0] == m.output_padding[1] and m.kernel_size[0] == m.kernel_size[1]
-            and not torch.is_autocast_enabled()):
+    if not (CONV_F32_MFMA and x.is_cuda and m.groups == 1 and tuple(m.dilation) == (1, 1) and m.stride[0] == m.stride[1]
+            and m.padding[0] == m.padding[1] and m.output_padding[0] == m.output_padding[1]
+            and m.kernel_size[0] == m.kernel_size[1] and m.weight.dtype in (_F32, _BF16)
+            and (x.dtype == _BF16 or (x.dtype == _F32 and m.weight.dtype == _F32 and not torch.is_autocast_enabled()))):
         return None
     return _ConvTransposeF32.apply(x, m.weight, m.bias, m.stride[0], m.padding[0], m.output_padding[0])
 

@@ -728,3 +728,49 @@ def test_engine_step_at_the_benchmarked_batch_vs_cpu_oracle(device, oracle_b12, 
     finally:
         rng.set_aug_buffer(None)
         rng.set_mode("device")
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_step_is_a_pure_function_of_state_inputs_and_seeds(device, bf16):
+    """No kernel of the step sums in a run-dependent order and no convolution is left to a library (MIOpen's igemm kernels
+    accumulate with atomics: round 3's "capture race"): two eager TrainEngine steps from the same snapshot and two
+    replays of the captured hipGraph agree BIT FOR BIT -- every loss, output, the 1 306 gradients and the whole post-step
+    state (weights after Adam, BatchNorm running statistics, depth-bin tracker) -- with the second-consumer alias handed to
+    the forked adapters (the topology round 3 parked).  64x96: the maps of stages 2 / 3 (4x6, 2x3) are the shapes the bf16
+    step's layout-specialised kernels refuse, i.e. the generic kernels of csrc/conv_f32.hip are part of the claim."""
+    from ppeadepth import rng
+    from ppeadepth.dist import TrainEngine
+    from ppeadepth.networks import replknet_adapter as rka
+    assert rka.BN_DUP_FORKED and rka.ADAPTER_STREAMS
+    B, H, W = 2, 64, 96
+    opt, model, tr = _build(device, B, H, W, use_checkpoint=True, amp=torch.bfloat16 if bf16 else None)
+    eng = TrainEngine(tr, lr=1e-4, bf16_params=bf16)
+    inputs = {k: v.to(device) for k, v in synth.make_inputs(B, H, W, smooth=True).items()}
+    snap = eng.snapshot()
+
+    def run():
+        eng.restore(snap)
+        torch.manual_seed(3)
+        random.seed(3)
+        outputs, losses = eng.step(dict(inputs) if eng.graph is None else inputs)
+        torch.cuda.synchronize()
+        res = {"loss:" + k: v.detach().clone() for k, v in losses.items()}
+        res.update({"out:" + str(k): v.detach().clone() for k, v in outputs.items() if torch.is_tensor(v)})
+        res.update({"grad:" + k: v.detach().clone() for k, v in eng.named_grads().items()})
+        res.update({"state:" + k: v.detach().clone() for k, v in model.state_dict().items()})
+        return res
+
+    try:
+        e1, e2 = run(), run()
+        eng.restore(snap)
+        torch.manual_seed(3)
+        random.seed(3)
+        eng.capture(inputs, warmup=1, restore_state=True)
+        g1, g2 = run(), run()
+    finally:
+        rng.set_aug_buffer(None)
+        rng.set_mode("device")
+    assert len([k for k in e1 if k.startswith("grad:")]) == 1306
+    for what, a in (("eager 2", e2), ("replay 1", g1), ("replay 2", g2)):
+        diff = [k for k in e1 if not torch.equal(e1[k], a[k])]
+        assert not diff, (what, len(diff), diff[:6])

@@ -35,6 +35,9 @@ def main():
     from ppeadepth import dist as pdist, networks, options, rng, synthetic as synth
     from ppeadepth.trainer import Trainer
     pdist.init_distributed("nccl")
+    from ppeadepth.networks import replknet_adapter as _rka
+    if args.alias_fork:
+        _rka.BN_DUP_FORKED = False                 # the "default" runs below: alias for the in-line adapters only
     dev = torch.device("cuda:0")
     B, H, W = args.B, args.H, args.W
     opt = options.default_options(height=H, width=W, batch_size=B, use_checkpoint=True)
@@ -100,7 +103,7 @@ def main():
         compare(g1, e1, "graph vs eager")
     if args.alias_fork:
         from ppeadepth.networks import replknet_adapter as rka
-        rka._DUP_FORK_DEBUG = True
+        rka.BN_DUP_FORKED = True
         eng.graph = None
         f1 = run("alias+fork eager")
         compare(f1, e1, "alias+fork eager vs default eager")

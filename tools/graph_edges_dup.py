@@ -230,7 +230,7 @@ def main():
     torch.cuda.CUDAGraph = _kept_graph
     pair_sets = {}
     for fork in (False, True):
-        rka._DUP_FORK_DEBUG = fork                 # the suspect topology: alias handed to the forked adapters too
+        rka.BN_DUP_FORKED = fork                 # the suspect topology: alias handed to the forked adapters too
         for i in range(args.captures if fork else 1):
             _GRAPHS.clear()
             res = T._engine_step(args.name, golden, dev, bf16=bf16, graph=True, **cfg)
