@@ -7,8 +7,14 @@
 //   forward : bn_stats (per-plane mean / M2)  ->  bn_finalize (per channel, updates running stats)
 //             -> bn_apply (one elementwise pass);
 //   backward: bn_bwd_reduce (per-plane sums of g and g*zhat) -> bn_bwd_finalize -> bn_bwd_apply.
-// Statistics are combined with Chan's parallel-variance formula (per-plane two-pass sums), so there
-// is no E[x^2] - mean^2 cancellation.  Layout NCHW, T = float or bf16 (fp32 math).
+// Statistics: the kernels that READ the activation (bn_stats, bn_stats_channel*, the channel kernels) take per-plane /
+// per-thread two-pass (mean, M2) and combine with Chan's parallel-variance formula: no E[x^2] - mean^2 cancellation.
+// The kernels that take their statistics from a PRODUCER's epilogue (bn_finalize_sums, bn_fwd_channel_sums; bn_sync.hip
+// bn_sums_to_packed; the fused-input finalize of dwconv_mfma.hip) receive fp32 per-tile (sum, sum of squares) partials,
+// add them in fp64 in a fixed order and form var = E[x^2] - mean^2 in fp64: exact up to the fp32 rounding of each tile's
+// partial, i.e. a relative variance error of ~1e-7 * (1 + mean^2 / var) -- 1e-3 for a channel with |mean| = 100 std
+// (pinned by tests/test_kernels_gpu.py::test_bn_statistics_from_epilogue_sums_with_a_large_mean; post-BatchNorm
+// activations of this network have |mean| / std of order 1).  Layout NCHW, T = float or bf16 (fp32 math).
 #include "bn_common.h"
 #include <cstdlib>
 

@@ -271,13 +271,14 @@ WgPlan plan(int N, int Cin, int Cout, int K, int stride, int Ho, int Wo) {
     const long per_slab = (long)K * K * p.CoutP * p.CinP * 4;
     long splits = (512 + tiles - 1) / tiles;                         // two waves of workgroups on 256 CUs
     const long want = splits;
-    const long cap = (32L << 20) / (per_slab * p.WK);                // workspace <= 32 MB ...
+    const long cap = (32L << 20) / (per_slab * p.WK);                // workspace <= 32 MB, or up to 4/3 of that (42.7 MB) ...
     if (splits > cap) splits = cap;
     // ... except that a layer never runs as fewer workgroups than CUs for want of workspace: 1024 -> 512 (19 MB per slab,
     // 128 tiles) ran as 128 workgroups walking 48 patches each -- 307 us against the library's 153; with 4 splits 184 us.
     // (More slabs everywhere -- a 128 MB cap -- was a net loss: every slab is a full-size fp32 gradient written and re-read.)
     // (the same for the layers whose cap leaves them a few workgroups short of one per CU: 512 -> 256 at 24 x 80 ran as
-    // 192 workgroups, 256 -> 128 at 48 x 160 as 216)
+    // 192 workgroups, 256 -> 128 at 48 x 160 as 216: they take `fill` splits when that stays within 4/3 of the cap; 9-16
+    // slabs are reduced by the flat kernel -- tests/test_kernels_gpu.py CONV_CASES wgrad_512_256_fill / wgrad_256_128_fill)
     long floor_splits = want < 4 ? want : 4;
     const long fill = (256 + tiles - 1) / tiles;
     if (fill <= want && fill > floor_splits && fill * 3 <= cap * 4) floor_splits = fill;

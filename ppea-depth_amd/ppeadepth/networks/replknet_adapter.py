@@ -34,7 +34,6 @@ def get_bn(channels):
 
 
 ADAPTER_STREAMS = os.environ.get("PPEA_ADAPTER_STREAMS", "1") == "1"   # adapters of the student on a forked side stream
-_SIDE = {}
 # The second-consumer alias of a block's first BatchNorm output (batchnorm.second_use) is handed to the FORKED adapters too
 # (round 4).  Round 3 recorded "wrong encoder gradients in 2 of 3 captures" for this topology and parked it; the cause was
 # not a capture race: tools/graph_edges_dup.py reads the captured hipGraph back (every kernel that touches the alias
@@ -46,13 +45,7 @@ BN_DUP_FORKED = os.environ.get("PPEA_BN_DUP_FORK", "1") == "1"
 NO_FORK_ON = set()       # cuda_stream handles on which adapters run inline (already a forked branch)
 
 
-def side_stream_of(main):
-    """The adapter side stream that belongs to `main` (created on first use)."""
-    key = (main.device.index, main.cuda_stream)
-    side = _SIDE.get(key)
-    if side is None:
-        side = _SIDE[key] = torch.cuda.Stream(main.device)
-    return side
+side_stream_of = ops.side_stream_of      # the adapter side stream that belongs to a stream (shared with the deferred wgrads)
 
 
 def _forked_adapter(adapter, inp):

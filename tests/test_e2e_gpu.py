@@ -236,7 +236,8 @@ TOL_F32 = dict(loss=1e-3, out=1e-3, l2=1e-3, share=5e-3, exact=0.0, grad_abs=2e-
 # eager fp32 at the other sizes is what the direct-path tests above already run; the engine adds the flat optimizer
 # layout, the step stream and the graph, which one eager case covers
 @pytest.mark.parametrize("name,graph", [("e2e_small", False), ("e2e_small", True), ("e2e_full", True),
-                                        ("e2e_l", True), ("e2e_dc", True), ("e2e_render", True)])
+                                        ("e2e_l", True), ("e2e_dc", True), ("e2e_render", True),
+                                        ("e2e_render_l", True), ("e2e_render_dc", True)])
 def test_engine_step_fp32_vs_reference_golden(device, golden, name, graph):
     """TrainEngine.step -- the object bench.py times -- in fp32, eager and replayed from a hipGraph: losses, disp /
     depth / warps / poses, cost-volume argmin maps, 15 gradients (sum, head, 4096-element sample), BN running
@@ -252,14 +253,14 @@ class _plain_torch_bf16:
     def __enter__(self):
         from ppeadepth import ops
         from ppeadepth.networks import replknet_adapter as rka
-        self.saved = (rka.FUSE_BN, rka.PW_MFMA, rka.ADAPTER_MFMA, ops._MFMA_K, ops.CONV_MFMA)
-        rka.FUSE_BN = rka.PW_MFMA = rka.ADAPTER_MFMA = ops.CONV_MFMA = False
+        self.saved = (rka.FUSE_BN, rka.PW_MFMA, rka.ADAPTER_MFMA, ops._MFMA_K, ops.CONV_MFMA, ops.CONV_F32_MFMA)
+        rka.FUSE_BN = rka.PW_MFMA = rka.ADAPTER_MFMA = ops.CONV_MFMA = ops.CONV_F32_MFMA = False
         ops._MFMA_K = ()
 
     def __exit__(self, *exc):
         from ppeadepth import ops
         from ppeadepth.networks import replknet_adapter as rka
-        rka.FUSE_BN, rka.PW_MFMA, rka.ADAPTER_MFMA, ops._MFMA_K, ops.CONV_MFMA = self.saved
+        rka.FUSE_BN, rka.PW_MFMA, rka.ADAPTER_MFMA, ops._MFMA_K, ops.CONV_MFMA, ops.CONV_F32_MFMA = self.saved
 
 
 # Absolute caps for the bf16 step (2x the values measured with tools/debug_bf16.py, profiles/r02_bf16_step_parity.txt).
@@ -331,23 +332,54 @@ RENDER_COS = {"depth.disp_convs.0.conv.weight": 1e-2, "depth.upconvs_0.0.conv.co
 # own bf16 autocast of the same model.
 
 
-def test_engine_step_bf16_on_the_rendered_fixture(device, golden):
+# The same construction for BASELINE config 4's model (RepLKNet-31L, e2e_render_l) and config 5 (`--dc`, 192x512,
+# e2e_render_dc): measured in profiles/r04_bf16_render_parity_{l,dc}.txt (eager == graph replay bit for bit); bounds = the
+# 31B fixture's where they hold with a factor of two to spare, else 2x the measured value.
+RENDER_ABS_OF = {
+    "e2e_render": RENDER_ABS,
+    "e2e_render_l": RENDER_ABS,
+    "e2e_render_dc": dict(RENDER_ABS, **{"loss:consistency_loss/0": 5e-3, "l2:translation|0|-1": 2.5e-2,
+                                         "l2:translation|0|1": 2.5e-2}),
+}
+RENDER_COS_OF = {
+    "e2e_render": RENDER_COS,
+    "e2e_render_l": dict(RENDER_COS, **{"mono_depth.upconvs_1.4.conv.conv.weight": 4.5e-2,
+                                        "mono_encoder.stages.2.blocks.35.mlp_adapter.D_fc1.bias": 9e-2}),
+    # Stage 2: the decoder is frozen, its adapter and the transposed conv train (repdepth.py:175-262)
+    "e2e_render_dc": {"depth.adapter.D_fc1.weight": 1e-2, "depth.adapter.D_fc2.weight": 1e-2, "depth.adapter.D_fc2.bias": 1e-2,
+                      "depth.deconv_adpt.weight": 1e-2, "depth.deconv_adpt.bias": 1e-2,
+                      "mono_depth.adapter.D_fc1.bias": 2e-2, "mono_depth.deconv_adpt.weight": 4e-2,
+                      "encoder.replk.stages.0.blocks.1.mlp_adapter.D_fc2.weight": 2e-2,
+                      "encoder.replk.stages.2.blocks.10.adapter.D_fc2.weight": 2e-2,
+                      "encoder.replk.stages.3.blocks.3.preffn_bn.weight": 4e-2,
+                      "mono_encoder.stages.2.blocks.35.mlp_adapter.D_fc1.bias": 7e-2},
+}
+
+
+@pytest.mark.parametrize("name", ["e2e_render", "e2e_render_l", "e2e_render_dc"])
+def test_engine_step_bf16_on_the_rendered_fixture(device, golden, name):
     """The benchmarked arithmetic (bf16 autocast, bf16 working weights with fp32 masters, every MFMA kernel), eager and
-    replayed from a hipGraph, against the reference's fp32 golden on the well-conditioned fixture: ABSOLUTE bounds, no
-    comparator, for losses, disp / depth, warps, poses, running statistics and the well-conditioned gradients."""
-    cfg = CONFIG_OF["e2e_render"]
+    replayed from a hipGraph, against the reference's fp32 golden on the well-conditioned fixture of EVERY benchmarked
+    model -- config 2 (31B), config 4 (31L) and config 5 (`--dc`): ABSOLUTE bounds, no comparator, for losses, disp /
+    depth, warps, poses, running statistics and the well-conditioned gradients; the replay must equal the eager step
+    bit for bit (losses, disp)."""
+    cfg = CONFIG_OF[name]
     with _plain_torch_bf16():
-        torch_err = _errors(*_engine_step("e2e_render", golden, device, bf16=True, graph=False, **cfg))
+        torch_err = _errors(*_engine_step(name, golden, device, bf16=True, graph=False, **cfg))
+    seen = []
     for graph in (False, True):
-        errs = _errors(*_engine_step("e2e_render", golden, device, bf16=True, graph=graph, **cfg))
-        bad = {k: (errs[k], b) for k, b in RENDER_ABS.items() if errs[k] > b}
-        for name, b in RENDER_COS.items():
-            if errs["grad_cos:" + name] > b:
-                bad["grad_cos:" + name] = (errs["grad_cos:" + name], b)
+        res = _engine_step(name, golden, device, bf16=True, graph=graph, **cfg)
+        errs = _errors(*res)
+        seen.append((res[5]["loss"].detach().clone(), res[4][("disp", 0)].detach().clone()))
+        bad = {k: (errs[k], b) for k, b in RENDER_ABS_OF[name].items() if errs[k] > b}
+        for key, b in RENDER_COS_OF[name].items():
+            if errs["grad_cos:" + key] > b:
+                bad["grad_cos:" + key] = (errs["grad_cos:" + key], b)
         for k, v in errs.items():
-            if k.startswith("grad_cos:") and k[9:] not in RENDER_COS and v > 1.5 * torch_err[k] + 2e-2:
+            if k.startswith("grad_cos:") and k[9:] not in RENDER_COS_OF[name] and v > 1.5 * torch_err[k] + 2e-2:
                 bad[k] = (v, "torch bf16", torch_err[k])
         assert not bad, (graph, bad)
+    assert torch.equal(seen[0][0], seen[1][0]) and torch.equal(seen[0][1], seen[1][1]), "graph replay != eager step"
 
 
 @pytest.mark.parametrize("cfg", ["b", "l", "dc"])
@@ -706,7 +738,8 @@ def test_engine_step_at_the_benchmarked_batch_vs_cpu_oracle(device, oracle_b12, 
         outputs, losses = eng.step(dev_inputs)
         torch.cuda.synchronize()
         grads = eng.named_grads()
-        tol_loss, tol_l2, tol_T, tol_cos = (3e-3, 2e-2, 1e-4, 2e-2) if bf16 else (1e-3, 1e-3, 1e-5, 1e-3)
+        # (bf16: the pose decoder's last conv rounds its ~100 m-scaled output to 8 bits: translation moves by ~5e-3 relative)
+        tol_loss, tol_l2, tol_T, tol_cos = (3e-3, 2e-2, 5e-3, 2e-2) if bf16 else (1e-3, 1e-3, 1e-5, 1e-3)
         bad = {}
         for k, v in ref_losses.items():
             e = rel_err(losses[k].detach().float().cpu(), v)

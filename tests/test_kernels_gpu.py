@@ -1024,6 +1024,10 @@ CONV_CASES = [
     ("big_32_1",       3, 32,  192, 640, 1,  3, 1,      1,   True,    "sigmoid", True,  False),
     ("big_64_48",      3, 64,  190, 630, 48, 3, 1,      1,   False,   "none",    False, False),
     ("big_40_16",      3, 40,  192, 640, 16, 3, 1,      1,   False,   "relu",    True,  False),
+    # the two decoder layers whose weight-gradient plan takes the "fill" splits beyond the 32 MB workspace cap (9-16 slabs,
+    # flat slab reduction; conv_wgrad.hip plan()), at the benchmarked batch and map size
+    ("wgrad_512_256_fill", 12, 512, 24, 80, 256, 3, 1,  1,   True,    "elu",     True,  False),
+    ("wgrad_256_128_fill", 12, 256, 48, 160, 128, 3, 1, 1,   True,    "elu",     True,  False),
 ]
 
 
@@ -1628,3 +1632,42 @@ def test_conv2d_f32_module_linear_and_transposed_conv(device):
     for m, r in zip((conv, lin, dec), ref):
         for (k, p), (_, q) in zip(m.named_parameters(), r.named_parameters()):
             assert rel_err(p.grad.cpu(), q.grad) < 2e-5, (type(m).__name__, k)
+
+
+def test_bn_statistics_from_epilogue_sums_with_a_large_mean(device):
+    """the BatchNorm kernels that take their statistics from the producing GEMM's epilogue sums form
+    var = E[x^2] - mean^2 (fp32 per-tile partials, fp64 combination).  Pinned against F.batch_norm in fp64 on channels with
+    |mean| / std from 1 to 100: the relative variance error stays below 3e-7 * (1 + (mean / std)^2) (outputs: 1e-3 of the
+    tensor's max at ratio 100, 2^-7 bf16 rounding below that), running statistics included."""
+    from ppeadepth import batchnorm, ops
+    from ppeadepth.networks import replknet_adapter as rka
+    g = _g(41)
+    B, K, M, H, W = 12, 64, 128, 12, 40
+    conv = rka.PointwiseConv(K, M, 1, 1, 0, 1, 1, False)
+    ratio = torch.tensor([1.0, 10.0, 30.0, 100.0]).repeat(M // 4)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(M, K, 1, 1, generator=g) / K ** 0.5)
+    conv.weight.requires_grad_(False)
+    conv = conv.to(device)
+    conv.weight.data = conv.weight.data.bfloat16()
+    bn = batchnorm.BatchNorm2d(M).to(device).train()
+    x = torch.randn(B, K, H, W, generator=g)
+    # a constant input channel with a large weight row sum shifts output channel m by ratio[m] standard deviations
+    x[:, 0] = 1.0
+    with torch.no_grad():
+        conv.weight[:, 0, 0, 0] = ratio.to(device).bfloat16()
+    xd = x.to(device).bfloat16()
+    z, sums = conv.forward_sums(xd, always=True)
+    assert sums is not None
+    y = batchnorm.fused_bn_act(z, bn, sums=sums)
+    zr = z.detach().double().cpu()
+    mean, var = zr.mean((0, 2, 3)), zr.var((0, 2, 3), unbiased=False)
+    assert float((mean.abs() / var.sqrt()).max()) > 60
+    yr = F.batch_norm(zr, None, None, bn.weight.detach().double().cpu(), bn.bias.detach().double().cpu(), True, 0.1, bn.eps)
+    assert rel_err(y.detach().float().cpu(), yr) < 2 ** -7 + 1e-3
+    n = B * H * W
+    got_var = (bn.running_var.double().cpu() - 0.9) / 0.1 * (n - 1) / n
+    rel = ((got_var - var).abs() / var)
+    bound = 3e-7 * (1 + (mean / var.sqrt()) ** 2) + 1e-6
+    assert bool((rel <= bound).all()), (rel / bound).max()
+    assert rel_err(bn.running_mean.double().cpu() / 0.1, mean) < 1e-6

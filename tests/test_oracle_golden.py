@@ -249,6 +249,23 @@ def test_e2e_stage2_decoder_adapter(golden):
     assert sd["depth.deconv_adpt.weight"].grad is not None
 
 
+@pytest.mark.slow
+def test_e2e_rendered_replknet31l(golden):
+    """The well-conditioned fixture for BASELINE config 4's model (RepLKNet-31L at 192x640): the absolute-bound pin of the
+    bf16 step of that config (tests/test_e2e_gpu.py::test_engine_step_bf16_on_the_rendered_fixture[e2e_render_l])."""
+    g = golden("e2e_render_l")
+    _check_e2e(g, *_run_e2e(g, rep_size="l", conditioned=True))
+
+
+@pytest.mark.slow
+def test_e2e_rendered_stage2_decoder_adapter(golden):
+    """The well-conditioned fixture for BASELINE config 5 (`--dc`, 192x512, Cityscapes intrinsics)."""
+    g = golden("e2e_render_dc")
+    outputs, losses, sd, tr, inputs, stride = _run_e2e(g, dc=True, intrinsics="cityscapes", conditioned=True)
+    _check_e2e(g, outputs, losses, sd, tr, inputs, stride)
+    assert sd["depth.upconvs_0.0.conv.conv.weight"].grad is None and sd["depth.deconv_adpt.weight"].grad is not None
+
+
 @pytest.mark.parametrize("size", ["b", "l"])
 def test_state_spec_matches_reference(size):
     """Names, shapes and the name-substring freeze rule (repdepth.py:47-50, 121-124)."""
