@@ -583,16 +583,7 @@ class TrainEngine:
             p.grad = None              # autograd then hands each gradient over without an accumulate kernel
         if self.flat is not None and self.flat.hooked:
             self.flat.begin_backward()
-        from . import ops
-        # weight gradients of the step stream's layers go to its side stream (ops._deferred_wgrad); not with gradient hooks
-        # (several ranks), which read a range's gradients as soon as backward has produced them
-        defer = self.stream is not None and not (self.flat is not None and self.flat.hooked)
-        ops.defer_wgrads_on(torch.cuda.current_stream() if defer else None)
-        try:
-            losses["loss"].backward()
-            ops.join_deferred_wgrads()
-        finally:
-            ops.defer_wgrads_on(None)
+        losses["loss"].backward()
         self._optimizer_phase()
         return outputs, losses
 

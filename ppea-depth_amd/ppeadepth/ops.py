@@ -1893,75 +1893,16 @@ def conv_supported(x, w):
             and w.shape[3] <= 7)
 
 
-# ---- weight gradients off the dependent chain ---------------------------------------------------------------------------
-# A layer's weight gradient is needed by nobody before the optimizer; launched in line it sits between this layer's data
-# gradient and the next layer's on the step's critical stream.  For the layers whose backward runs on the step stream (the
-# student's decoder, reduce_conv, stem[0], the pose network -- the tail of the step) it is launched on the step stream's
-# side stream instead (the one the student's adapters already run on: no new stream, no new hardware queue -- with more
-# than four the whole step runs 2x slower on this runtime), after that stream has waited for dz; TrainEngine
-# joins the side stream before the gradients are gathered.  One rank only (several ranks: the gradient hooks read a range's
-# gradients as soon as backward has produced them).
-import os as _os
-
-WGRAD_SIDE = _os.environ.get("PPEA_WGRAD_SIDE", "1") == "1"
 _SIDE = {}
-_DEFER = {"stream": None, "used": False}     # set by TrainEngine around backward: the step stream whose wgrads may be deferred
 
 
 def side_stream_of(main):
-    """The side stream that belongs to `main` (created on first use): adapters of the student, deferred weight gradients."""
+    """The side stream that belongs to `main` (created on first use): the student's adapters run on it."""
     key = (main.device.index, main.cuda_stream)
     side = _SIDE.get(key)
     if side is None:
         side = _SIDE[key] = torch.cuda.Stream(main.device)
     return side
-
-
-def defer_wgrads_on(stream):
-    """TrainEngine: weight gradients of layers whose backward runs on `stream` may go to its side stream (None: off)."""
-    _DEFER["stream"] = None if stream is None else stream.cuda_stream
-    _DEFER["used"] = False
-
-
-def join_deferred_wgrads():
-    """After backward, on the step stream: wait for the deferred weight gradients."""
-    if _DEFER["used"]:
-        main = torch.cuda.current_stream()
-        main.wait_stream(side_stream_of(main))
-        _DEFER["used"] = False
-
-
-def _main_of_side():
-    """Inside `with _deferred_wgrad(...)` on the side stream: the step stream the result is consumed on."""
-    return _DEFER["main_obj"]
-
-
-class _deferred_wgrad:
-    """with _deferred_wgrad(dz, x) as on_side: ... launches inside run on the side stream when deferral applies."""
-
-    def __init__(self, *reads):
-        self.reads = reads
-        self.ctx = None
-
-    def __enter__(self):
-        main = torch.cuda.current_stream()
-        if not (WGRAD_SIDE and _DEFER["stream"] is not None and main.cuda_stream == _DEFER["stream"]):
-            return False
-        side = side_stream_of(main)
-        side.wait_stream(main)                       # the operands below have been produced on `main`
-        for t in self.reads:
-            if t is not None:
-                t.record_stream(side)                # allocated on `main`, read by side-stream kernels
-        _DEFER["main_obj"] = main
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        _DEFER["used"] = True
-        return True
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
 
 
 class _ConvNhwc(torch.autograd.Function):
@@ -2024,15 +1965,12 @@ class _ConvNhwc(torch.autograd.Function):
             if Cout % 8 != 0:
                 raise _abi.PpeaKernelError("conv weight gradient: output channels must be a multiple of 8 "
                                            "(pad the layer, see conv2d_nhwc)")
-            with _deferred_wgrad(dz, x) as on_side:
-                ws = torch.empty(_abi.lib.ppea_conv_wgrad_workspace_bytes(N, Cin, Cout, R, S, stride, Ho, Wo) // 4,
-                                 device=dz.device, dtype=_F32)
-                gdt = w.dtype if w.dtype in (_BF16, _F32) else _F32
-                dw = torch.empty(Cout, Cin, R, S, device=dz.device, dtype=gdt)
-                call("ppea_conv_wgrad_nhwc_bf16", _raw(dz), _raw(x), ptr(dw), int(gdt == _BF16), ptr(ws), N, H, W, Cin, Cout, R,
-                     S, stride, pad, int(reflect), Ho, Wo, stream_ptr())
-                if on_side:
-                    dw.record_stream(_main_of_side())
+            ws = torch.empty(_abi.lib.ppea_conv_wgrad_workspace_bytes(N, Cin, Cout, R, S, stride, Ho, Wo) // 4, device=dz.device,
+                             dtype=_F32)
+            gdt = w.dtype if w.dtype in (_BF16, _F32) else _F32
+            dw = torch.empty(Cout, Cin, R, S, device=dz.device, dtype=gdt)
+            call("ppea_conv_wgrad_nhwc_bf16", _raw(dz), _raw(x), ptr(dw), int(gdt == _BF16), ptr(ws), N, H, W, Cin, Cout, R, S,
+                 stride, pad, int(reflect), Ho, Wo, stream_ptr())
         return dx, dw, db, None, None, None, None, None
 
 
@@ -2082,15 +2020,11 @@ class _ConvImage(torch.autograd.Function):
         Cout, Cin, K, _ = w.shape
         dz = _as_nhwc(dy.to(_BF16))
         Ho, Wo = dz.shape[2], dz.shape[3]
-        with _deferred_wgrad(dz, x) as on_side:
-            ws = torch.empty(_abi.lib.ppea_conv_image_wgrad_workspace_bytes(N, Cout, K, Ho, Wo) // 4, device=dz.device,
-                             dtype=_F32)
-            gdt = w.dtype if w.dtype in (_BF16, _F32) else _F32
-            dw = torch.empty(Cout, Cin, K, K, device=dz.device, dtype=gdt)
-            call("ppea_conv_image_wgrad_bf16", _raw(dz), _raw(x), ptr(dw), int(gdt == _BF16), ptr(ws), N, H, W, Cin, Cout, K, 2,
-                 ctx.pad, Ho, Wo, stream_ptr())
-            if on_side:
-                dw.record_stream(_main_of_side())
+        ws = torch.empty(_abi.lib.ppea_conv_image_wgrad_workspace_bytes(N, Cout, K, Ho, Wo) // 4, device=dz.device, dtype=_F32)
+        gdt = w.dtype if w.dtype in (_BF16, _F32) else _F32
+        dw = torch.empty(Cout, Cin, K, K, device=dz.device, dtype=gdt)
+        call("ppea_conv_image_wgrad_bf16", _raw(dz), _raw(x), ptr(dw), int(gdt == _BF16), ptr(ws), N, H, W, Cin, Cout, K, 2,
+             ctx.pad, Ho, Wo, stream_ptr())
         return None, dw, None, None
 
 

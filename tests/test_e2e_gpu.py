@@ -243,7 +243,13 @@ def test_engine_step_fp32_vs_reference_golden(device, golden, name, graph):
     depth / warps / poses, cost-volume argmin maps, 15 gradients (sum, head, 4096-element sample), BN running
     statistics and the depth-bin tracker against the reference's unmodified process_batch + backward."""
     res = _engine_step(name, golden, device, bf16=False, graph=graph, **CONFIG_OF.get(name, {}))
-    _assert_within(_errors(*res), TOL_F32)
+    tol = TOL_F32
+    if name == "e2e_render_l":
+        # the first 32 elements of pose.net.3.weight's gradient are sums with heavy cancellation on this fixture: 5.05e-2 of
+        # their max between two fp32 executions, while the same tensor's 4096-element sample agrees to 1.1e-2 in L2 and
+        # 6e-5 in cosine (profiles/r04_bf16_render_parity_l.txt, column fp32)
+        tol = dict(TOL_F32, grad_head=8e-2)
+    _assert_within(_errors(*res), tol)
 
 
 class _plain_torch_bf16:
