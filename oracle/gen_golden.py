@@ -248,6 +248,11 @@ DC_GRAD_KEYS = [k for k in GRAD_KEYS if not k.startswith(("depth.", "mono_depth.
     "mono_depth.deconv_adpt.weight"]
 
 
+TI_GRAD_KEYS = GRAD_KEYS + ["encoder.replk.input_adapter.D_fc1.weight", "encoder.replk.input_adapter.bn2.weight",
+                            "encoder.replk.trans_adpt.0.D_fc1.weight", "encoder.replk.trans_adpt.2.D_fc2.bias",
+                            "mono_encoder.input_adapter.D_fc2.weight", "mono_encoder.trans_adpt.1.D_fc2.weight"]
+
+
 def gen_e2e(name, B, H, W, extra=(), stride=1, seed=1, grad_keys=None, intrinsics="kitti", conditioned=False):
     """Unmodified Trainer.process_batch + backward of the reference (config-1 style).
     conditioned: rendered frames (synth.make_rendered_inputs) + the well-conditioned weight variant
@@ -299,6 +304,35 @@ def gen_e2e(name, B, H, W, extra=(), stride=1, seed=1, grad_keys=None, intrinsic
     mn, mx = tr.depth_bin_tracker.compute()
     arrays["bins_after"] = torch.stack([mn.reshape(()), mx.reshape(())])
     save(name, **arrays)
+
+
+def gen_dec_designs():
+    """The reference's DepthDecoderV2 with every Stage-2 decoder-adapter design (`--dec_id` 1-4, 8, 10;
+    depth_decoder_v2.py:135-245) standalone on seeded RepLKNet-31B-shaped features: disparity, the gradients of the four
+    feature maps and every parameter gradient's (sum, abs sum, 32-element head) for the back-propagated seed."""
+    from ppeadepth.networks.depth_decoder_v2 import DepthDecoderV2
+    ch = np.array([128, 256, 512, 1024])
+    B, h, w = 2, 16, 24
+    arrays = {"meta": np.array([B, h, w])}
+    for tid in (1, 2, 3, 4, 8, 10):
+        torch.manual_seed(0)
+        dec = DepthDecoderV2(ch, range(4), False, dc=True, test_id=tid)
+        synth.fill_state_dict(dec)
+        dec.train()
+        feats = [rnd(B, int(ch[i]), h >> i, w >> i, seed=20 + i).requires_grad_(True) for i in range(4)]
+        disp = dec(feats)[("disp", 0)]
+        go = rnd(*disp.shape, seed=31)
+        disp.backward(go)
+        arrays[f"{tid}:disp"] = disp[..., ::2, ::2]
+        arrays[f"{tid}:names"] = np.array(list(dec.state_dict().keys()))
+        for i, f in enumerate(feats):                  # (spatially subsampled where large: fixtures stay small)
+            arrays[f"{tid}:dfeat{i}"] = f.grad[..., ::4, ::4] if i == 0 else (f.grad[..., ::2, ::2] if i == 1 else f.grad)
+        for k, p_ in dec.named_parameters():
+            g = p_.grad
+            arrays[f"{tid}:gsum:{k}"] = g.double().sum().float()
+            arrays[f"{tid}:gabs:{k}"] = g.double().abs().sum().float()
+            arrays[f"{tid}:ghead:{k}"] = g.reshape(-1)[:32].clone()
+    save("dec_designs", **arrays)
 
 
 def gen_eval():
@@ -378,6 +412,10 @@ GENERATORS = {
     "e2e_render": lambda: gen_e2e("e2e_render", 2, 192, 640, stride=8, conditioned=True),
     # the same well-conditioned construction for BASELINE config 4's model (RepLKNet-31L) at full size and for config 5
     # (Stage-2 `--dc`, 192x512, Cityscapes intrinsics): absolute bounds for the bf16 step of every benchmarked model
+    # the `--trans` / `--input` adapters of both encoders (replknet_adapter.py:112-149, 429-458, 511-540)
+    "e2e_ti": lambda: gen_e2e("e2e_ti", 2, 64, 96, extra=["--trans", "--input", "--mono_trans", "--mono_input"],
+                              grad_keys=TI_GRAD_KEYS),
+    "dec_designs": gen_dec_designs,
     "e2e_render_l": lambda: gen_e2e("e2e_render_l", 2, 192, 640, extra=["--rep_size", "l"], stride=8, conditioned=True),
     "e2e_render_dc": lambda: gen_e2e("e2e_render_dc", 2, 192, 512, extra=["--dc"], stride=8, grad_keys=DC_GRAD_KEYS,
                                      intrinsics="cityscapes", conditioned=True),

@@ -7,9 +7,20 @@
 // the chip (10.8 MB/img algorithmic).  A second kernel does the per-pixel
 // work over the bin axis (missing -> max, confidence, argmin, lowest-cost depth).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
+// Two horizontally adjacent samples of a feature row in one 8-byte load: the address is only 4-byte aligned (x0 is any
+// column), which gfx950 global loads allow.
+struct alignas(4) Pair { float a, b; };
+
+// One thread = one pixel x DB consecutive depth bins.  The kernel is bound by vector-memory instruction issue (gathers
+// that hit L1 / L2: the lookup map is 3.9 MB per item), not by bytes, so the loads are what is economised: the current
+// frame's feature is read once per channel for all DB bins (it does not depend on the bin), and a bilinear corner pair is
+// one 8-byte load -- (1 + 2 * 2 * DB) / DB = 2.25 loads per (pixel, bin, channel) at DB = 4 instead of 5.
+// Same arithmetic, in the same order, as the one-bin form (pinned bit for bit by test_cost_volume_golden's argmin).
+template <int DB>
 __global__ __launch_bounds__(256) void cost_volume_fwd(const float* __restrict__ cur,
                                                        const float* __restrict__ lookup,
                                                        const float* __restrict__ P,
@@ -18,56 +29,103 @@ __global__ __launch_bounds__(256) void cost_volume_fwd(const float* __restrict__
                                                        const int32_t* __restrict__ skip,
                                                        float* __restrict__ cost, int C, int h, int w, int D,
                                                        float eps) {
-    const int b = blockIdx.z, d = blockIdx.y;
+    const int b = blockIdx.z, d0 = blockIdx.y * DB;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int hw = h * w;
     if (i >= hw) return;
-    float* outp = cost + ((long)b * D + d) * hw + i;
-    if (skip != nullptr && skip[b] != 0) { *outp = 0.f; return; }
+    float* outp = cost + ((long)b * D + d0) * hw + i;
+    const int nd = min(DB, D - d0);
     const int py = i / w, px = i - py * w;
     // the 2-pixel border of the current frame is masked out (rkm.py:315-317)
-    if (px < 2 || px >= w - 2 || py < 2 || py >= h - 2) { *outp = 0.f; return; }
+    if ((skip != nullptr && skip[b] != 0) || px < 2 || px >= w - 2 || py < 2 || py >= h - 2) {
+        for (int k = 0; k < nd; ++k) outp[(long)k * hw] = 0.f;
+        return;
+    }
     const float* ik = inv_K + b * 16;
     const float* pm = P + b * 12;
     const float fx = (float)px, fy = (float)py;
-    const float depth = bins[d];
-    float X[3];
+    float ray[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) X[k] = depth * ((ik[k * 4] * fx + ik[k * 4 + 1] * fy) + ik[k * 4 + 2]);
-    float cam[3];
+    for (int k = 0; k < 3; ++k) ray[k] = (ik[k * 4] * fx + ik[k * 4 + 1] * fy) + ik[k * 4 + 2];
+    long off[DB];                      // y0 * w + x0 of the top-left corner; -1: outside the edge mask (cost 0)
+    float w00[DB], w01[DB], w10[DB], w11[DB];
+    bool pair_ok[DB];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        cam[k] = ((pm[k * 4] * X[0] + pm[k * 4 + 1] * X[1]) + pm[k * 4 + 2] * X[2]) + pm[k * 4 + 3];
-    const float iz = cam[2] + eps;
-    // normalised grid exactly as Project3D builds it, then both consumers' un-normalisations
-    const float gx = ((cam[0] / iz) / (float)(w - 1) - 0.5f) * 2.f;
-    const float gy = ((cam[1] / iz) / (float)(h - 1) - 0.5f) * 2.f;
-    const float xv = (gx / 2.f + 0.5f) * (float)(w - 1);          // edge-mask coordinates (:306-308)
-    const float yv = (gy / 2.f + 0.5f) * (float)(h - 1);
-    if (!(xv >= 2.0f && xv <= (float)(w - 2) && yv >= 2.0f && yv <= (float)(h - 2))) { *outp = 0.f; return; }
-    const float ix = ((gx + 1.f) / 2.f) * (float)(w - 1);         // grid_sample coordinates
-    const float iy = ((gy + 1.f) / 2.f) * (float)(h - 1);
-    const float flx = floorf(ix), fly = floorf(iy);
-    const int x0 = (int)flx, y0 = (int)fly;
-    const float tx = ix - flx, ty = iy - fly;
-    const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
-    // inside the edge mask x0 >= 1 and x0 + 1 <= w - 1 unless ix == w-2 exactly... keep the checks
-    const bool in_x1 = (x0 + 1 < w), in_y1 = (y0 + 1 < h);
-    const float* lk = lookup + (long)b * C * hw + (long)y0 * w + x0;
-    const float* cu = cur + (long)b * C * hw + i;
-    double acc = 0.0;
-    for (int c = 0; c < C; ++c) {
-        const float* l = lk + (long)c * hw;
-        const float v00 = l[0];
-        const float v01 = in_x1 ? l[1] : 0.f;
-        const float v10 = in_y1 ? l[w] : 0.f;
-        const float v11 = (in_x1 && in_y1) ? l[w + 1] : 0.f;
-        const float warped = ((v00 * w00 + v01 * w01) + v10 * w10) + v11 * w11;
-        acc += (double)fabsf(warped - cu[(long)c * hw]);
+    for (int k = 0; k < DB; ++k) {
+        off[k] = -1;
+        pair_ok[k] = false;
+        w00[k] = w01[k] = w10[k] = w11[k] = 0.f;
+        if (k >= nd) continue;
+        const float depth = bins[d0 + k];
+        float X[3], cam[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) X[q] = depth * ray[q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            cam[q] = ((pm[q * 4] * X[0] + pm[q * 4 + 1] * X[1]) + pm[q * 4 + 2] * X[2]) + pm[q * 4 + 3];
+        const float iz = cam[2] + eps;
+        // normalised grid exactly as Project3D builds it, then both consumers' un-normalisations
+        const float gx = ((cam[0] / iz) / (float)(w - 1) - 0.5f) * 2.f;
+        const float gy = ((cam[1] / iz) / (float)(h - 1) - 0.5f) * 2.f;
+        const float xv = (gx / 2.f + 0.5f) * (float)(w - 1);          // edge-mask coordinates (:306-308)
+        const float yv = (gy / 2.f + 0.5f) * (float)(h - 1);
+        if (!(xv >= 2.0f && xv <= (float)(w - 2) && yv >= 2.0f && yv <= (float)(h - 2))) continue;
+        const float ix = ((gx + 1.f) / 2.f) * (float)(w - 1);         // grid_sample coordinates
+        const float iy = ((gy + 1.f) / 2.f) * (float)(h - 1);
+        const float flx = floorf(ix), fly = floorf(iy);
+        const int x0 = (int)flx, y0 = (int)fly;
+        const float tx = ix - flx, ty = iy - fly;
+        w00[k] = (1.f - tx) * (1.f - ty); w01[k] = tx * (1.f - ty); w10[k] = (1.f - tx) * ty; w11[k] = tx * ty;
+        // inside the edge mask the 2 x 2 footprint lies inside the map; a footprint that touches the last column / row
+        // (ix == w - 2 rounded up) takes the corner-by-corner path with zero fill, as grid_sample does
+        pair_ok[k] = (x0 + 1 < w) && (y0 + 1 < h);
+        off[k] = (long)y0 * w + x0;
+        if (!pair_ok[k]) {              // rare: resolve here, once, with scalar loads
+            const float* lk = lookup + (long)b * C * hw + off[k];
+            const float* cu = cur + (long)b * C * hw + i;
+            double acc = 0.0;
+            for (int c = 0; c < C; ++c) {
+                const float* l = lk + (long)c * hw;
+                const float v00 = l[0];
+                const float v01 = (x0 + 1 < w) ? l[1] : 0.f;
+                const float v10 = (y0 + 1 < h) ? l[w] : 0.f;
+                const float v11 = 0.f;
+                const float warped = ((v00 * w00[k] + v01 * w01[k]) + v10 * w10[k]) + v11 * w11[k];
+                acc += (double)fabsf(warped - cu[(long)c * hw]);
+            }
+            const float diff = (float)(acc / (double)C);
+            outp[(long)k * hw] = diff / ((diff > 0.f ? 1.f : 0.f) + 1e-7f);
+            off[k] = -2;                // done
+        }
     }
-    const float diff = (float)(acc / (double)C);
-    // single lookup frame: volume = diff / ((diff > 0) + 1e-7)   (:323-326)
-    *outp = diff / ((diff > 0.f ? 1.f : 0.f) + 1e-7f);
+    const float* lkb = lookup + (long)b * C * hw;
+    const float* cu = cur + (long)b * C * hw + i;
+    double acc[DB];
+#pragma unroll
+    for (int k = 0; k < DB; ++k) acc[k] = 0.0;
+    for (int c = 0; c < C; ++c) {
+        const float cv = cu[(long)c * hw];
+        const float* lc = lkb + (long)c * hw;
+#pragma unroll
+        for (int k = 0; k < DB; ++k) {
+            if (off[k] < 0) continue;
+            const Pair top = *reinterpret_cast<const Pair*>(lc + off[k]);
+            const Pair bot = *reinterpret_cast<const Pair*>(lc + off[k] + w);
+            const float warped = ((top.a * w00[k] + top.b * w01[k]) + bot.a * w10[k]) + bot.b * w11[k];
+            acc[k] += (double)fabsf(warped - cv);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DB; ++k) {
+        if (k >= nd || off[k] == -2) continue;
+        float v = 0.f;
+        if (off[k] >= 0) {
+            const float diff = (float)(acc[k] / (double)C);
+            // single lookup frame: volume = diff / ((diff > 0) + 1e-7)   (:323-326)
+            v = diff / ((diff > 0.f ? 1.f : 0.f) + 1e-7f);
+        }
+        outp[(long)k * hw] = v;
+    }
 }
 
 __global__ __launch_bounds__(256) void cost_volume_reduce(const float* __restrict__ cost,
@@ -113,9 +171,13 @@ int ppea_cost_volume_fwd_f32(const float* cur, const float* lookup, const float*
                              int D, float eps, void* stream) {
     if (B < 0 || C <= 0 || h < 5 || w < 5 || D <= 0 || D > 65535) return PPEA_ERR_UNSUPPORTED;
     if (B == 0) return 0;
-    dim3 g((h * w + 255) / 256, D, B);
-    hipLaunchKernelGGL(cost_volume_fwd, g, dim3(256), 0, (hipStream_t)stream, cur, lookup, P, inv_K, bins,
-                       skip, cost, C, h, w, D, eps);
+    const char* e = getenv("PPEA_CV_DB");
+    const int db = e ? atoi(e) : 4;
+#define CV_LAUNCH(DB_)                                                                                              \
+    hipLaunchKernelGGL(cost_volume_fwd<DB_>, dim3((h * w + 255) / 256, (D + DB_ - 1) / DB_, B), dim3(256), 0,         \
+                       (hipStream_t)stream, cur, lookup, P, inv_K, bins, skip, cost, C, h, w, D, eps)
+    if (db == 1) CV_LAUNCH(1); else if (db == 2) CV_LAUNCH(2); else if (db == 8) CV_LAUNCH(8); else CV_LAUNCH(4);
+#undef CV_LAUNCH
     return launch_status();
 }
 

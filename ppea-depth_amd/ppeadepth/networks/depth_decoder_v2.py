@@ -47,6 +47,30 @@ class Adapter(nn.Module):
         return ops.pw_linear(self.act(pre).to(torch.bfloat16), w2, self.D_fc2.bias)
 
 
+class Adapter_(nn.Module):
+    """dec.py:53-78 (design 10): zero-initialised Linear(C_in -> C_out) -> GELU -> nearest 2x upsampling."""
+
+    def __init__(self, D_features_in, D_features_out, mlp_ratio=0.25, act_layer=nn.GELU):
+        super().__init__()
+        self.act = act_layer()
+        self.D_fc1 = nn.Linear(int(D_features_in), int(D_features_out))
+        nn.init.constant_(self.D_fc1.weight, 0)
+        nn.init.constant_(self.D_fc1.bias, 0)
+
+    def forward(self, x):
+        from .replknet_adapter import channel_linear
+        return F.interpolate(self.act(channel_linear(x, self.D_fc1)), scale_factor=2, mode="nearest")
+
+
+def _deconv(m, x):
+    """nn.ConvTranspose2d on this build's kernels (bf16 step: implicit GEMM; fp32 step / other shapes: conv_f32.hip)."""
+    from .. import ops
+    y = ops.conv_transpose_module(m, x)
+    if y is None:
+        y = ops.conv_transpose_f32_module(m, x)
+    return m(x) if y is None else y
+
+
 class DepthDecoderV2(nn.Module):
     def __init__(self, num_ch_enc, scales=range(4), debug=False, num_output_channels=1, use_skips=True,
                  dc=False, test_id=1):
@@ -69,31 +93,53 @@ class DepthDecoderV2(nn.Module):
             self.add_decoder_adapter(test_id)
 
     def add_decoder_adapter(self, test_id, mlp_ratio=0.25):
-        """dec.py:135-169 / repdepth.py:199-203: design 1 (dec_id 1/5/6/7)."""
-        if test_id not in (1, 5, 6, 7):
-            raise NotImplementedError("decoder-adapter designs other than dec_id 1/5/6/7 are out of scope")
-        c = int(self.ch_in_disp[0])
-        self.adapter = Adapter(int(self.num_ch_enc[-1]) + int(self.num_ch_enc[0]), c, mlp_ratio=mlp_ratio)
-        self.deconv_adpt = nn.ConvTranspose2d(c, c, 3, 2, 1, output_padding=1)
-        nn.init.constant_(self.deconv_adpt.weight, 0)
-        nn.init.constant_(self.deconv_adpt.bias, 0)
+        """dec.py:135-169 / repdepth.py:175-262: the Stage-2 decoder adapter, every design of the reference (`--dec_id`):
+        1 / 5 / 6 / 7 general adapter on cat(f0, up8(f3)) + transposed conv; 2 all four feature maps; 3 the deepest one
+        only; 4 a second transposed conv instead of the final upsampling; 8 no transposed conv; 10 one zero-initialised
+        `Adapter_` per decoder level added to the level's output."""
+        c, ch = int(self.ch_in_disp[0]), [int(v) for v in self.num_ch_enc]
+
+        def deconv():
+            m = nn.ConvTranspose2d(c, c, 3, 2, 1, output_padding=1)
+            nn.init.constant_(m.weight, 0)
+            nn.init.constant_(m.bias, 0)
+            return m
+        if test_id in (1, 5, 6, 7, 4, 8):
+            # (repdepth.py:199-203: only designs 1 / 5 / 6 take --dec_ratio; the others keep the default 0.25)
+            self.adapter = Adapter(ch[3] + ch[0], c, mlp_ratio=mlp_ratio if test_id in (1, 5, 6) else 0.25)
+        elif test_id == 2:
+            self.adapter = Adapter(ch[3] + ch[2] + ch[1] + ch[0], c)
+        elif test_id == 3:
+            self.adapter = Adapter(ch[3], c)
+        elif test_id == 10:
+            self.adapters = nn.ModuleList([Adapter_(ch[3 - i], ch[2 - i]) for i in range(3)] + [Adapter_(ch[0], ch[0] // 2)])
+        else:
+            raise ValueError(f"--dec_id {test_id}: the reference defines designs 1-8 and 10 (depth_decoder_v2.py:135-169)")
+        if test_id in (1, 2, 3, 4, 5, 6, 7):
+            self.deconv_adpt = deconv()
+        if test_id == 4:
+            self.deconv_adpt2 = deconv()
         self.dc, self.test_id = True, test_id
 
     def forward(self, input_features):
         self.outputs = {}
         adpt_out = None
-        if self.dc:
-            from .. import ops
-            # Stage-2 decoder adapter (dec.py:178-182, 230-233) on the NCHW encoder features
-            a = self.adapter.forward_split(input_features[0], input_features[-1], 8)
-            if a is None:
-                x_up = F.interpolate(input_features[-1], scale_factor=8, mode="nearest")
-                a = self.adapter(torch.cat([input_features[0], x_up], 1))
-            adpt_out = ops.conv_transpose_module(self.deconv_adpt, a)
-            if adpt_out is None:
-                adpt_out = ops.conv_transpose_f32_module(self.deconv_adpt, a)        # fp32 step: csrc/conv_f32.hip
-            if adpt_out is None:
-                adpt_out = self.deconv_adpt(a)
+        tid = self.test_id
+        if self.dc and tid < 10:
+            # Stage-2 decoder adapter (dec.py:172-200) on the NCHW encoder features
+            f0, f3 = input_features[0], input_features[-1]
+            if tid in (1, 4, 5, 6, 7, 8):
+                a = self.adapter.forward_split(f0, f3, 8)
+                if a is None:
+                    a = self.adapter(torch.cat([f0, F.interpolate(f3, scale_factor=8, mode="nearest")], 1))
+            elif tid == 2:
+                a = self.adapter(torch.cat([f0, F.interpolate(f3, scale_factor=8, mode="nearest"),
+                                            F.interpolate(input_features[-2], scale_factor=4, mode="nearest"),
+                                            F.interpolate(input_features[1], scale_factor=2, mode="nearest")], 1))
+            else:
+                a = self.adapter(F.interpolate(f3, scale_factor=8, mode="nearest"))
+            adpt_out = F.interpolate(a, scale_factor=2, mode="nearest") if tid == 8 else _deconv(self.deconv_adpt, a)
+        level_adapters = self.adapters if (self.dc and tid >= 10) else None
         if NHWC and input_features[-1].is_cuda:
             # the decoder's 3x3 convolutions are implicit GEMMs over channels-last operands (csrc/conv_nhwc.hip): hand them
             # channels_last activations once here (pad / bias + ELU have channels_last kernels, upsample and concat keep
@@ -101,10 +147,16 @@ class DepthDecoderV2(nn.Module):
             input_features = [f.contiguous(memory_format=torch.channels_last) for f in input_features]
         x = input_features[-1]
         for i in range(4):
+            lvl = level_adapters[i](x) if level_adapters is not None else None          # design 10 (dec.py:203-218)
             x = upsample_cat(self.upconvs_0[i](x), input_features[2 - i] if i < 3 else None)
             x = self.upconvs_1[i](x)
+            if lvl is not None:
+                x = x + 0.01 * lvl.to(x.dtype)
         x = self.upconvs_1[-1](upsample_cat(self.upconvs_0[-1](x)))
-        if self.dc:
-            x = x + F.interpolate(adpt_out, scale_factor=2).to(x.dtype)    # (autocast runs the interpolation in fp32)
+        if adpt_out is not None:
+            if tid == 4:
+                x = x + _deconv(self.deconv_adpt2, adpt_out).to(x.dtype)
+            else:
+                x = x + F.interpolate(adpt_out, scale_factor=2).to(x.dtype)    # (autocast runs the interpolation in fp32)
         self.outputs[("disp", 0)] = self.disp_convs[0](x, act="sigmoid")          # sigmoid in the conv's epilogue
         return self.outputs

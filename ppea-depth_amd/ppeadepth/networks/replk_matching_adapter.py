@@ -107,11 +107,11 @@ class RepLKMatchingAdapter(nn.Module):
         if x is None:
             x = self.reduce_conv(cat)
         self.replk.plan_drop_masks(x, stages=range(1, self.replk.num_stages))
-        x = self.replk.transitions[0](x)
+        x = self.replk.transition_forward(0, x)
         for s in range(1, self.replk.num_stages):
             x = self.replk.stages[s](x)
             if s in self.replk.out_indices:
                 self.features.append(self.replk.stages[s].norm(x))
             if s < self.replk.num_stages - 1:
-                x = self.replk.transitions[s](x)
+                x = self.replk.transition_forward(s, x)
         return self.features, lowest_cost, confidence_mask

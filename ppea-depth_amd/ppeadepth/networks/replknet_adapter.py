@@ -316,6 +316,26 @@ class B_Adapter(nn.Module):
         return h
 
 
+class InputAdapter(nn.Module):
+    """rka.py:134-149 (`--input` / `--mono_input`): Conv3x3 s2 (C -> C/4) -> BN -> GELU -> Conv3x3 (C/4 -> C) -> BN on the
+    output of stem[0], added to the output of the stem.  Plain (not Sync) BatchNorm in the reference."""
+
+    def __init__(self, D_features, mlp_ratio=0.25, act_layer=nn.GELU):
+        super().__init__()
+        hidden = int(D_features * mlp_ratio)
+        self.D_fc1 = ops.Conv2d(D_features, hidden, 3, 2, 1)
+        self.D_fc2 = ops.Conv2d(hidden, D_features, 3, 1, 1)
+        self.act = act_layer()
+        self.bn1 = BatchNorm2d(hidden)
+        self.bn2 = BatchNorm2d(D_features)
+
+    def forward(self, x):
+        if FUSE_BN and self.training and x.is_cuda:
+            h = fused_bn_act(self.D_fc1(x), self.bn1, act=ops.ACT_GELU)
+            return fused_bn_act(self.D_fc2(h), self.bn2)
+        return self.bn2(self.D_fc2(self.act(self.bn1(self.D_fc1(x)))))
+
+
 class ReparamLargeKernelConv(nn.Module):
     """rka.py:210-261.  Training form: BN(DW_k(x)) + BN(DW_5(x)); both depthwise convs come out of one
     launch that stages x in LDS once."""
@@ -579,8 +599,6 @@ class RepLKNetAdapter(nn.Module):
         super().__init__()
         if num_classes is not None and out_indices is not None:
             raise ValueError("cannot specify both num_classes (for pretraining) and out_indices")
-        if trans_adpt or input_adpt:
-            raise NotImplementedError("--trans / --input adapters are outside the hot-path scope (SURVEY 2)")
         self.out_indices = out_indices
         if use_sync_bn:
             enable_sync_bn()
@@ -588,7 +606,6 @@ class RepLKNetAdapter(nn.Module):
         self.use_checkpoint = use_checkpoint
         self.num_stages = len(layers)
         self.num_input_images = num_input_images
-        self.trans_adpt, self.input_adpt = False, False
         bw = channels[0]
         self.stem = nn.ModuleList([
             conv_bn_relu(in_channels * num_input_images, bw, 3, 2, 1, 1),
@@ -600,6 +617,14 @@ class RepLKNetAdapter(nn.Module):
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(layers))]
         self.stages = nn.ModuleList()
         self.transitions = nn.ModuleList()
+        # rka.py:429-436: `--input` adapter on the stem, `--trans` adapters (+ DropPath) after every transition
+        self.input_adpt = bool(input_adpt)
+        if input_adpt:
+            self.input_adapter = InputAdapter(bw)
+        self.trans_adpt = False
+        if trans_adpt:
+            self.trans_adpt = nn.ModuleList()
+            self.trans_drop_path = nn.ModuleList()
         for s in range(self.num_stages):
             self.stages.append(RepLKNetStage(
                 channels[s], layers[s], large_kernel_sizes[s], dpr[sum(layers[:s]):sum(layers[:s + 1])],
@@ -609,6 +634,9 @@ class RepLKNetAdapter(nn.Module):
                 self.transitions.append(nn.Sequential(
                     conv_bn_relu(channels[s], channels[s + 1], 1, 1, 0, 1),
                     conv_bn_relu(channels[s + 1], channels[s + 1], 3, 2, 1, channels[s + 1])))
+                if trans_adpt:
+                    self.trans_adpt.append(Adapter(channels[s + 1], adpt_test))
+                    self.trans_drop_path.append(DropPath(dpr[sum(layers[:s])]))
         if num_classes is not None:
             self.norm = get_bn(channels[-1])
             self.avgpool = nn.AdaptiveAvgPool2d(1)
@@ -634,8 +662,18 @@ class RepLKNetAdapter(nn.Module):
         self.load_state_dict(weights, strict=False)
 
     def stem_forward(self, x):
-        for layer in self.stem:
+        """rka.py:511-521: the stem, with the `--input` adapter branching off stem[0]'s output."""
+        x = self.stem[0](x)
+        adpt = self.input_adapter(x) if self.input_adpt else None
+        for layer in self.stem[1:]:
             x = layer(x)
+        return x if adpt is None else x + adpt
+
+    def transition_forward(self, s, x):
+        """rka.py:537-540: transition s followed, with `--trans`, by x + DropPath(Adapter(x))."""
+        x = self.transitions[s](x)
+        if self.trans_adpt:
+            x = x + self.trans_drop_path[s](self.trans_adpt[s](x))
         return x
 
     def plan_drop_masks(self, x, stages=None):
@@ -652,7 +690,7 @@ class RepLKNetAdapter(nn.Module):
             if self.out_indices is not None and s in self.out_indices:
                 outs.append(self.stages[s].norm(x))
             if s < self.num_stages - 1:
-                x = self.transitions[s](x)
+                x = self.transition_forward(s, x)
         return x if self.out_indices is None else outs
 
     def forward(self, x):

@@ -18,11 +18,11 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 
 
-def _build(device, B, H, W, use_checkpoint=False, amp=None, rep_size="b", dc=False, conditioned=False):
+def _build(device, B, H, W, use_checkpoint=False, amp=None, rep_size="b", dc=False, conditioned=False, **flags):
     from ppeadepth import networks, options, rng
     from ppeadepth.trainer import Trainer
     opt = options.default_options(height=H, width=W, batch_size=B, use_checkpoint=use_checkpoint, rep_size=rep_size,
-                                  dc=dc)
+                                  dc=dc, **flags)
     model = networks.RepDepth(opt)
     if dc:
         model.dc_ft_init()                       # reference Trainer.__init__, trainer.py:158-161
@@ -45,14 +45,16 @@ def _key(k):
 # how each golden was generated (oracle/gen_golden.py GENERATORS)
 CONFIG_OF = {"e2e_small_ckpt": dict(use_checkpoint=True), "e2e_l": dict(rep_size="l"),
              "e2e_dc": dict(dc=True, intrinsics="cityscapes"), "e2e_render": dict(conditioned=True),
+             "e2e_ti": dict(trans=True, input=True, mono_trans=True, mono_input=True),
              "e2e_render_l": dict(conditioned=True, rep_size="l"),
              "e2e_render_dc": dict(conditioned=True, dc=True, intrinsics="cityscapes")}
 
 
-def _run(golden_name, golden, device, use_checkpoint=False, rep_size="b", dc=False, intrinsics="kitti", conditioned=False):
+def _run(golden_name, golden, device, use_checkpoint=False, rep_size="b", dc=False, intrinsics="kitti", conditioned=False,
+         **flags):
     g = golden(golden_name)
     B, H, W, stride, seed = (int(v) for v in g["meta"])
-    opt, model, tr = _build(device, B, H, W, use_checkpoint, rep_size=rep_size, dc=dc, conditioned=conditioned)
+    opt, model, tr = _build(device, B, H, W, use_checkpoint, rep_size=rep_size, dc=dc, conditioned=conditioned, **flags)
     inputs = {k: v.to(device) for k, v in _inputs(B, H, W, intrinsics, conditioned).items()}
     torch.manual_seed(seed)
     random.seed(seed)
@@ -62,7 +64,7 @@ def _run(golden_name, golden, device, use_checkpoint=False, rep_size="b", dc=Fal
 
 
 def _engine_step(golden_name, golden, device, bf16, graph, use_checkpoint=False, rep_size="b", dc=False,
-                 intrinsics="kitti", conditioned=False):
+                 intrinsics="kitti", conditioned=False, **flags):
     """ONE training step through `TrainEngine` -- the object bench.py times -- from the golden's initial state and with
     the reference's random draws: bf16 = autocast + bf16 working weights with fp32 masters (MFMA kernels), graph =
     the whole step replayed from a hipGraph (state restored after the capture's warm-up steps)."""
@@ -71,7 +73,7 @@ def _engine_step(golden_name, golden, device, bf16, graph, use_checkpoint=False,
     g = golden(golden_name)
     B, H, W, stride, seed = (int(v) for v in g["meta"])
     opt, model, tr = _build(device, B, H, W, use_checkpoint, amp=torch.bfloat16 if bf16 else None,
-                            rep_size=rep_size, dc=dc, conditioned=conditioned)
+                            rep_size=rep_size, dc=dc, conditioned=conditioned, **flags)
     eng = TrainEngine(tr, lr=1e-4, bf16_params=bf16)
     inputs = {k: v.to(device) for k, v in _inputs(B, H, W, intrinsics, conditioned).items()}
     try:
@@ -215,6 +217,59 @@ def test_e2e_rendered_well_conditioned_vs_reference_golden(device, golden):
 def test_e2e_replknet31l_vs_reference_golden(device, golden):
     """BASELINE config 4's model: RepLKNet-31L (C = 192/384/768/1536), fp32, reduced frame size."""
     _check(*_run("e2e_l", golden, device, rep_size="l"))
+
+
+def test_e2e_trans_and_input_adapters_vs_reference_golden(device, golden):
+    """`--trans --input --mono_trans --mono_input` (replknet_adapter.py:112-149, 429-458, 511-540; matching encoder
+    replk_matching_adapter.py:347-354, 461-472): the input adapter on stem[0]'s output and an Adapter + DropPath after every
+    transition, in both encoders, against the reference's unmodified process_batch + backward."""
+    g, model, tr, inputs, outputs, losses, stride = _run("e2e_ti", golden, device, **CONFIG_OF["e2e_ti"])
+    _check(g, model, tr, inputs, outputs, losses, stride)
+    for k in ("encoder.replk.input_adapter.D_fc1.weight", "mono_encoder.trans_adpt.1.D_fc2.weight"):
+        assert dict(model.named_parameters())[k].grad is not None
+
+
+@pytest.mark.parametrize("tid", [1, 2, 3, 4, 8, 10])
+def test_decoder_adapter_designs_vs_reference_golden(device, golden, tid):
+    """Every Stage-2 decoder-adapter design of the reference (`--dec_id`, depth_decoder_v2.py:135-245) standalone on seeded
+    features, fp32: disparity, feature gradients and every parameter gradient against the reference's own DepthDecoderV2;
+    then the bf16 path of the same module (implicit-GEMM transposed conv, MFMA adapters or the generic kernels) within bf16
+    rounding of the fp32 result."""
+    import numpy as np
+    from ppeadepth.networks.depth_decoder_v2 import DepthDecoderV2
+    g = golden("dec_designs")
+    B, h, w = (int(v) for v in g["meta"])
+    ch = np.array([128, 256, 512, 1024])
+    dec = DepthDecoderV2(ch, range(4), False, dc=True, test_id=tid)
+    names = [str(n) for n in np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "dec_designs.npz"))[f"{tid}:names"]]
+    assert list(dec.state_dict().keys()) == names
+    synth.fill_state_dict(dec)
+    dec.to(device).train()
+
+    def feats_():
+        gs = [torch.Generator().manual_seed(20 + i) for i in range(4)]
+        return [torch.randn(B, int(ch[i]), h >> i, w >> i, generator=gs[i]).to(device).requires_grad_(True) for i in range(4)]
+    feats = feats_()
+    disp = dec(feats)[("disp", 0)]
+    go = torch.randn(disp.shape, generator=torch.Generator().manual_seed(31)).to(device)
+    disp.backward(go)
+    assert rel_err(disp.detach().cpu()[..., ::2, ::2], g[f"{tid}:disp"]) < 1e-4
+    for i, f in enumerate(feats):
+        mine = f.grad.cpu()
+        mine = mine[..., ::4, ::4] if i == 0 else (mine[..., ::2, ::2] if i == 1 else mine)
+        assert rel_err(mine, g[f"{tid}:dfeat{i}"]) < 2e-4, i
+    for k, p in dec.named_parameters():
+        gr = p.grad.double().cpu()
+        scale = float(g[f"{tid}:gabs:{k}"]) + 1e-12
+        assert abs(float(gr.abs().sum()) - scale) / scale < 1e-3, k
+        assert abs(float(gr.sum()) - float(g[f"{tid}:gsum:{k}"])) / scale < 1e-3, k
+        head = g[f"{tid}:ghead:{k}"]
+        assert (gr.reshape(-1)[:32].float() - head).abs().max() / (head.abs().max() + 1e-12) < 2e-3, k
+    # bf16 (autocast, fp32 parameters): same module
+    f16 = feats_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        d16 = dec([f.bfloat16() for f in f16])[("disp", 0)]
+    assert rel_err(d16.float().cpu(), disp.detach().cpu()) < 3e-2
 
 
 def test_e2e_stage2_decoder_adapter_vs_reference_golden(device, golden):
