@@ -35,7 +35,8 @@ def pytest_collection_modifyitems(config, items):
 
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
-        return {k: torch.from_numpy(z[k]) for k in z.files}
+        # numeric arrays as tensors; string arrays (state_dict key lists) stay numpy
+        return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiub" else z[k]) for k in z.files}
 
 
 @pytest.fixture(scope="session")

@@ -241,8 +241,7 @@ def test_decoder_adapter_designs_vs_reference_golden(device, golden, tid):
     B, h, w = (int(v) for v in g["meta"])
     ch = np.array([128, 256, 512, 1024])
     dec = DepthDecoderV2(ch, range(4), False, dc=True, test_id=tid)
-    names = [str(n) for n in np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "dec_designs.npz"))[f"{tid}:names"]]
-    assert list(dec.state_dict().keys()) == names
+    assert list(dec.state_dict().keys()) == [str(n) for n in g[f"{tid}:names"]]
     synth.fill_state_dict(dec)
     dec.to(device).train()
 
