@@ -498,6 +498,12 @@ int ppea_cost_volume_fwd_f32(const float* cur, const float* lookup, const float*
                              const float* inv_K, const float* bins, const int32_t* skip,
                              float* cost, int B, int C, int h, int w, int D, float eps,
                              void* stream);
+/* bf16 features (the bf16 step): the kernel is bound by the bytes crossing the L1, so channel PAIRS are packed into dwords
+ * first (`pairs`: caller-owned workspace of 2 * B * C/2 * h * w uint32) and a corner load serves two channels.  Bit-identical
+ * to ppea_cost_volume_fwd_f32 on the features widened to fp32.  C even. */
+int ppea_cost_volume_fwd_bf16(const void* cur, const void* lookup, void* pairs, const float* P, const float* inv_K,
+                              const float* bins, const int32_t* skip, float* cost, int B, int C, int h, int w, int D,
+                              float eps, void* stream);
 int ppea_cost_volume_reduce_f32(const float* cost, const float* bins, float* cost_out,
                                 float* confidence, int64_t* argmin, float* lowest,
                                 int B, int D, int h, int w, void* stream);

@@ -156,6 +156,7 @@ SIGNATURES = {
     "ppea_conv2d_bf16_dgrad": [_vp] * 5 + [_i] * 11 + [_vp],
     "ppea_conv2d_bf16_wgrad": [_vp] * 6 + [_i] * 11 + [_vp],
     "ppea_cost_volume_fwd_f32": [_vp] * 7 + [_i] * 5 + [_f, _vp],
+    "ppea_cost_volume_fwd_bf16": [_vp] * 8 + [_i] * 5 + [_f, _vp],
     "ppea_cost_volume_reduce_f32": [_vp] * 6 + [_i] * 4 + [_vp],
 }
 

@@ -97,7 +97,7 @@ class RepLKMatchingAdapter(nn.Module):
             lookup_feats, _ = self.feature_extraction(lookup_images.reshape(B * Fr, ch, H, W))
             if callable(poses):
                 poses = poses()
-            raw = ops.cost_volume(self.features[-1].float(), lookup_feats.float(), poses[:, 0], K, invK,
+            raw = ops.cost_volume(self.features[-1], lookup_feats, poses[:, 0], K, invK,
                                   self.depth_bins)
             cost_volume, confidence_mask, argmin, lowest_cost = ops.cost_volume_reduce(raw, self.depth_bins)
         self.argmin = argmin

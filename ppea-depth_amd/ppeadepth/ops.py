@@ -431,16 +431,26 @@ def loss_select(reproj, identity, warped_m1, warped_p1, noise, selec_reproj=True
 # ---------------------------------------------------------------------------------------------
 # A9/A10  cost volume (runs under no_grad in the reference, rkm.py:427)
 # ---------------------------------------------------------------------------------------------
+CV_BF16 = True      # bf16 features on the packed-pair kernel (False: widened to fp32 first; bit-identical results)
+
+
 @torch.no_grad()
 def cost_volume(cur, lookup, poses, K, inv_K, bins, eps=1e-7):
     """cur, lookup [B,C,h,w]; poses [B,4,4] (zeroed pose = skipped item); -> raw cost [B,D,h,w]."""
-    cur = cur.contiguous().float()
-    lookup = lookup.contiguous().float()
     B, C, h, w = cur.shape
     D = bins.shape[0]
     P = torch.matmul(K, poses)[:, :3, :].contiguous().float()
     skip = (poses.reshape(B, -1).sum(1) == 0).to(torch.int32)
     cost = torch.empty(B, D, h, w, device=cur.device, dtype=_F32)
+    if CV_BF16 and cur.dtype == _BF16 and lookup.dtype == _BF16 and C % 2 == 0:
+        # bf16 features: channel pairs packed into dwords (half the bytes through the L1), same arithmetic
+        pairs = torch.empty(2 * B * (C // 2) * h * w, device=cur.device, dtype=torch.int32)
+        call("ppea_cost_volume_fwd_bf16", ptr(cur.contiguous()), ptr(lookup.contiguous()), ptr(pairs), ptr(P),
+             ptr(inv_K.contiguous().float()), ptr(bins.contiguous().float()), ptr(skip), ptr(cost), B, C, h, w, D, float(eps),
+             stream_ptr())
+        return cost
+    cur = cur.contiguous().float()
+    lookup = lookup.contiguous().float()
     call("ppea_cost_volume_fwd_f32", ptr(cur), ptr(lookup), ptr(P), ptr(inv_K.contiguous().float()),
          ptr(bins.contiguous().float()), ptr(skip), ptr(cost), B, C, h, w, D, float(eps), stream_ptr())
     return cost

@@ -1671,3 +1671,30 @@ def test_bn_statistics_from_epilogue_sums_with_a_large_mean(device):
     bound = 3e-7 * (1 + (mean / var.sqrt()) ** 2) + 1e-6
     assert bool((rel <= bound).all()), (rel / bound).max()
     assert rel_err(bn.running_mean.double().cpu() / 0.1, mean) < 1e-6
+
+
+def test_cost_volume_bf16_packed_pairs_is_bit_identical_to_the_fp32_kernel(device):
+    """The bf16 step's cost volume (channel pairs packed into dwords: half the bytes through the L1) against the fp32 kernel
+    on the same features widened to fp32: same arithmetic in the same order -> identical bits, incl. a skipped item (zeroed
+    pose), the 2-pixel border mask and footprints that leave the map; C = 30 (odd pair count), ragged map."""
+    from oracle import synth
+    from ppeadepth import ops
+    g = _g(23)
+    B, C, h, w, D = 3, 30, 21, 37, 13
+    cur = torch.randn(B, C, h, w, generator=g).bfloat16().to(device)
+    look = torch.randn(B, C, h, w, generator=g).bfloat16().to(device)
+    K, inv_K = synth.kitti_K(4 * h, 4 * w, 2)
+    K, inv_K = K[None].repeat(B, 1, 1).to(device), inv_K[None].repeat(B, 1, 1).to(device)
+    T = torch.eye(4)[None].repeat(B, 1, 1)
+    T[:, 2, 3], T[:, 0, 3] = 0.8, 0.3
+    T[1] = 0.0                                                    # skipped item (repdepth.py:561-575)
+    T = T.to(device)
+    bins = torch.exp(torch.linspace(-2.3, 2.3, D)).to(device)
+    a = ops.cost_volume(cur, look, T, K, inv_K, bins)
+    saved, ops.CV_BF16 = ops.CV_BF16, False
+    try:
+        b = ops.cost_volume(cur, look, T, K, inv_K, bins)
+    finally:
+        ops.CV_BF16 = saved
+    assert torch.equal(a, b)
+    assert float((a[0] != 0).float().mean()) > 0.2 and float(a[1].abs().max()) == 0.0
