@@ -472,6 +472,14 @@ int ppea_conv2d_bf16_dgrad(const void* dy, const long* dys, const void* w, void*
 int ppea_conv2d_bf16_wgrad(const void* x, const long* xs, const void* dy, const long* dys, float* dw, float* workspace, int N,
                            int Cin, int H, int W, int Cout, int R, int S, int stride, int pad, int Ho, int Wo, void* stream);
 
+/* MaxPool2d(3, 2, 1) of the pose ResNet-18 (networks/resnet_encoder.py:376-392) on channels-last tensors
+ * (csrc/nhwc_pool.hip): forward keeps a one-byte window index (3 r + s, torch's tie rule: first maximum in scan order), the
+ * backward gathers (no atomics).  x [N][H][W][C], C % 8 == 0; y, idx [N][Ho][Wo][C] with Ho = (H - 1) / 2 + 1. */
+int ppea_nhwc_maxpool3x3s2_fwd_f32(const void* x, void* y, void* idx, int N, int H, int W, int C, void* stream);
+int ppea_nhwc_maxpool3x3s2_fwd_bf16(const void* x, void* y, void* idx, int N, int H, int W, int C, void* stream);
+int ppea_nhwc_maxpool3x3s2_bwd_f32(const void* dy, const void* idx, void* dx, int N, int H, int W, int C, void* stream);
+int ppea_nhwc_maxpool3x3s2_bwd_bf16(const void* dy, const void* idx, void* dx, int N, int H, int W, int C, void* stream);
+
 /* Image-fed convolutions (csrc/conv_image.hip): RepLKNet stem[0] (networks/replknet_adapter.py:411, 3x3 stride 2) and
  * the pose ResNet-18 conv1 (networks/resnet_encoder.py:376-388, 7x7 stride 2).  The frame is channels-last bf16 with its
  * 3 / 6 channels zero-padded to 8 (ppea_image_to_nhwc_bf16); one MFMA contraction covers a whole filter ROW (S taps x 8

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libppea_depth.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
@@ -156,6 +156,10 @@ SIGNATURES = {
     "ppea_conv2d_bf16_dgrad": [_vp] * 5 + [_i] * 11 + [_vp],
     "ppea_conv2d_bf16_wgrad": [_vp] * 6 + [_i] * 11 + [_vp],
     "ppea_cost_volume_fwd_f32": [_vp] * 7 + [_i] * 5 + [_f, _vp],
+    "ppea_nhwc_maxpool3x3s2_fwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_maxpool3x3s2_fwd_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_maxpool3x3s2_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_nhwc_maxpool3x3s2_bwd_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_cost_volume_fwd_bf16": [_vp] * 8 + [_i] * 5 + [_f, _vp],
     "ppea_cost_volume_reduce_f32": [_vp] * 6 + [_i] * 4 + [_vp],
 }

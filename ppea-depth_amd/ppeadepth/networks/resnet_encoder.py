@@ -105,6 +105,12 @@ def _conv(c, x):
     return c(x) if y is None else y
 
 
+def _maxpool(m, x):
+    """MaxPool2d(3, 2, 1) of the trunk: gather kernels on channels_last HIP tensors, the module otherwise."""
+    y = ops.maxpool3x3s2(x) if (x.is_cuda and m.kernel_size == 3 and m.stride == 2 and m.padding == 1) else None
+    return m(x) if y is None else y
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -230,7 +236,7 @@ class ResnetEncoder(nn.Module):
             # normalisation, bf16 rounding (what autocast feeds conv1), 6 -> 8 channels and channels_last in one kernel
             x = ops.image_to_nhwc(input_image, 8, 0.45, 0.225)
             self.features = [e.bn1.fused(_conv(e.conv1, x), 1)]
-            self.features.append(e.layer1(e.maxpool(self.features[-1])))
+            self.features.append(e.layer1(_maxpool(e.maxpool, self.features[-1])))
             self.features.append(e.layer2(self.features[-1]))
             self.features.append(e.layer3(self.features[-1]))
             self.features.append(e.layer4(self.features[-1]))
@@ -243,7 +249,7 @@ class ResnetEncoder(nn.Module):
             x = x.contiguous(memory_format=torch.channels_last)
         self.features = [e.bn1.fused(e.conv1(x), 1) if (FUSED_NHWC_BN and self.training and x.is_cuda)
                          else e.relu(e.bn1(e.conv1(x)))]
-        self.features.append(e.layer1(e.maxpool(self.features[-1])))
+        self.features.append(e.layer1(_maxpool(e.maxpool, self.features[-1])))
         self.features.append(e.layer2(self.features[-1]))
         self.features.append(e.layer3(self.features[-1]))
         self.features.append(e.layer4(self.features[-1]))

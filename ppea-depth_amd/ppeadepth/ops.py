@@ -1078,6 +1078,39 @@ def nhwc_bn_act(x, weight, bias, running_mean, running_var, res=None, act=ACT_NO
 
 
 # ---------------------------------------------------------------------------------------------
+# pose trunk: MaxPool2d(3, 2, 1) on channels_last tensors (csrc/nhwc_pool.hip)          resnet_encoder.py:376-392
+# ---------------------------------------------------------------------------------------------
+class _MaxPoolNhwc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+        idx = torch.empty(N, Ho, Wo, C, device=x.device, dtype=torch.uint8)
+        call(f"ppea_nhwc_maxpool3x3s2_fwd_{_suffix(x)}", _raw(x), _raw(y), ptr(idx), N, H, W, C, stream_ptr())
+        ctx.save_for_backward(idx)
+        ctx.dims = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, C, H, W = ctx.dims
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty(N, C, H, W, device=dy.device, dtype=dy.dtype, memory_format=torch.channels_last)
+        call(f"ppea_nhwc_maxpool3x3s2_bwd_{_suffix(dy)}", _raw(dy), ptr(idx), _raw(dx), N, H, W, C, stream_ptr())
+        return dx
+
+
+def maxpool3x3s2(x):
+    """nn.MaxPool2d(3, 2, 1)(x) for a channels_last HIP tensor (C % 8 == 0, fp32 / bf16) on the gather kernels; None when
+    this call is not served."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (_F32, _BF16) and x.shape[1] % 8 == 0 and _is_nhwc(x)):
+        return None
+    return _MaxPoolNhwc.apply(x)
+
+
+# ---------------------------------------------------------------------------------------------
 # A12 glue: bias + ELU of ConvBlock                                         layers.py:103-116
 # ---------------------------------------------------------------------------------------------
 def _is_nhwc(t):

@@ -1698,3 +1698,29 @@ def test_cost_volume_bf16_packed_pairs_is_bit_identical_to_the_fp32_kernel(devic
         ops.CV_BF16 = saved
     assert torch.equal(a, b)
     assert float((a[0] != 0).float().mean()) > 0.2 and float(a[1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(3, 64, 24, 40), (2, 16, 13, 19), (24, 64, 96, 320)])
+def test_maxpool3x3s2_nhwc_equals_torch(device, dtype, shape):
+    """MaxPool2d(3, 2, 1) of the pose trunk on channels_last tensors (csrc/nhwc_pool.hip) against F.max_pool2d: outputs and
+    the input gradient EXACTLY (post-ReLU input: about half the entries are exact zeros, so the tie rule -- first maximum
+    in scan order -- decides most windows), odd map sizes, the benchmarked [24,64,96,320]."""
+    from ppeadepth import ops
+    g = _g(sum(shape))
+    dt = torch.float32 if dtype == "f32" else torch.bfloat16
+    x = torch.relu(torch.randn(*shape, generator=g)).to(dt)
+    xr = x.clone().to(device).requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    go = torch.randn(yr.shape, generator=g).to(dt).to(device)
+    yr.backward(go)
+    xd = x.to(device).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.maxpool3x3s2(xd)
+    assert y is not None and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(go)
+    assert torch.equal(y.detach(), yr.detach())
+    if dtype == "f32":
+        assert torch.equal(xd.grad, xr.grad)
+    else:       # torch accumulates the (up to four) bf16 contributions of a pixel in its own order; here: fp32 sum, one rounding
+        assert rel_err(xd.grad.float().cpu(), xr.grad.float().cpu()) < 2 ** -7
+        assert float((xd.grad != xr.grad).float().mean()) < 0.02
