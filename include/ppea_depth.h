@@ -402,6 +402,21 @@ int ppea_loss_select_f32(const float* reproj, const float* identity, const float
                          uint8_t* src_idx, int64_t* frame_idx, int64_t* auto_idx,
                          int B, int C, int H, int W, int selec_reproj, void* stream);
 
+/* Tail of compute_losses (trainer.py:1092-1139) after the per-pixel selection: mask (automask argmin == 0, or for the
+ * multi-frame pass consistency_mask * (1 - augmentation_mask)), rl = sum(sel * mask) / (sum(mask) + 1e-7), and for the
+ * multi-frame pass the consistency loss mean(|multi - mono| * (1 - mask)) and its target.  One pass + finalize forward, one
+ * pass backward (d reproj [B][2][H][W] routed by the selection's source index, d multi_depth); fixed summation order.
+ *   sel, mask, target, multi, mono [B][1][H][W] fp32; auto_idx int64 or NULL; cons [B][H][W] or NULL; aug [B] or NULL;
+ *   partial: ppea_loss_tail_blocks(B*H*W) * 3 floats; out[0] = rl, out[1] = consistency loss, out[2] = 1/(sum(mask)+1e-7);
+ *   g_rl / g_con: device scalars (gradients of out[0] / out[1]) or NULL. */
+int ppea_loss_tail_blocks(long total);
+int ppea_loss_tail_fwd_f32(const float* sel, const int64_t* auto_idx, const float* cons, const float* aug, const float* multi,
+                           const float* mono, float* mask, float* target, float* partial, float* out, int B, int H, int W,
+                           int is_multi, void* stream);
+int ppea_loss_tail_bwd_f32(const float* mask, const uint8_t* src, const float* out, const float* g_rl, const float* g_con,
+                           const float* multi, const float* mono, float* d_reproj, float* d_multi, int B, int H, int W,
+                           void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * A12 / A14  Dense convolutions as implicit GEMMs on the matrix cores (csrc/conv_nhwc.hip, conv_wgrad.hip):
  *     bf16 channels-last activations, fp32 accumulation.  Replaces the library convolutions behind

@@ -297,6 +297,104 @@ __global__ __launch_bounds__(256) void loss_select(const float* __restrict__ rep
     auto_idx[i] = (idm < v || (idm != idm && v == v)) ? 1 : 0;
 }
 
+
+// ---- the tail of compute_losses (trainer.py:1092-1139) --------------------------------------------------------------------
+// After the per-pixel selection: the (auto)mask / motion mask, the masked mean of the reprojection loss
+// rl = sum(sel * mask) / (sum(mask) + 1e-7), and for the multi-frame pass the consistency term
+// mean(|multi_depth - mono_depth| * (1 - mask)) and its target 1 / (mono * cm + multi * (1 - cm)).  The reference issues ~20
+// element-wise / reduction kernels per pass for this (and autograd as many again backward); here: one pass + a finalize
+// forward, one pass backward, sums in a fixed order (per-block partials, then one block in fp64).
+constexpr int TAIL_TPB = 256, TAIL_PER = 4;
+
+__global__ __launch_bounds__(TAIL_TPB) void loss_tail_fwd(const float* __restrict__ sel, const int64_t* __restrict__ auto_idx,
+                                                          const float* __restrict__ cons, const float* __restrict__ aug,
+                                                          const float* __restrict__ multi, const float* __restrict__ mono,
+                                                          float* __restrict__ mask_out, float* __restrict__ target,
+                                                          float* __restrict__ partial, long hw, long total, int is_multi) {
+    __shared__ float red[3][TAIL_TPB / 64];
+    float s_num = 0.f, s_den = 0.f, s_con = 0.f;
+    const long base = ((long)blockIdx.x * TAIL_TPB + threadIdx.x) * TAIL_PER;
+#pragma unroll
+    for (int k = 0; k < TAIL_PER; ++k) {
+        const long i = base + k;
+        if (i >= total) break;
+        float m;
+        if (!is_multi) {
+            m = (auto_idx == nullptr) ? 1.f : (auto_idx[i] == 0 ? 1.f : 0.f);
+        } else {
+            m = 1.f;
+            if (cons != nullptr) m = m * cons[i];
+            if (aug != nullptr) m = m * (1.f - aug[i / hw]);
+        }
+        mask_out[i] = m;
+        s_num += sel[i] * m;
+        s_den += m;
+        if (is_multi) {
+            const float cm = 1.f - m;
+            const float a = multi[i], b = mono[i];
+            s_con += fabsf(a - b) * cm;
+            target[i] = 1.f / (b * cm + a * (1.f - cm));
+        }
+    }
+    s_num = wave_sum(s_num); s_den = wave_sum(s_den); s_con = wave_sum(s_con);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wv] = s_num; red[1][wv] = s_den; red[2][wv] = s_con; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < TAIL_TPB / 64; ++w) t += red[threadIdx.x][w];
+        partial[(long)blockIdx.x * 3 + threadIdx.x] = t;
+    }
+}
+
+// out[0] = rl, out[1] = consistency loss, out[2] = 1 / (sum(mask) + 1e-7)
+__global__ __launch_bounds__(256) void loss_tail_finalize(const float* __restrict__ partial, int nblk, long total,
+                                                          float* __restrict__ out) {
+    __shared__ double red[3][256];
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) { a += partial[i * 3]; b += partial[i * 3 + 1]; c += partial[i * 3 + 2]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b; red[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float num = (float)red[0][0], den = (float)red[1][0] + 1e-7f;
+        out[0] = num / den;
+        out[1] = (float)(red[2][0] / (double)total);
+        out[2] = 1.f / den;
+    }
+}
+
+// d_reproj[b][c][p] = g_rl * mask * inv_den if src[b][p] == c else 0 (c = 0, 1; src == 2: the selection forced zero);
+// d_multi = g_con * sign(multi - mono) * (1 - mask) / total
+__global__ __launch_bounds__(256) void loss_tail_bwd(const float* __restrict__ mask, const uint8_t* __restrict__ src,
+                                                     const float* __restrict__ out, const float* __restrict__ g_rl,
+                                                     const float* __restrict__ g_con, const float* __restrict__ multi,
+                                                     const float* __restrict__ mono, float* __restrict__ d_reproj,
+                                                     float* __restrict__ d_multi, long hw, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float m = mask[i];
+    if (d_reproj != nullptr) {
+        const float g = (g_rl != nullptr ? g_rl[0] : 0.f) * m * out[2];
+        const long b = i / hw, p = i - b * hw;
+        const int sidx = src[i];
+        d_reproj[b * 2 * hw + p] = sidx == 0 ? g : 0.f;
+        d_reproj[b * 2 * hw + hw + p] = sidx == 1 ? g : 0.f;
+    }
+    if (d_multi != nullptr) {
+        const float d = multi[i] - mono[i];
+        const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+        d_multi[i] = (g_con != nullptr ? g_con[0] : 0.f) * sg * (1.f - m) / (float)total;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -350,6 +448,33 @@ int ppea_loss_select_f32(const float* reproj, const float* identity, const float
     hipLaunchKernelGGL(loss_select, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        reproj, identity, warped_m1, warped_p1, noise, sel, src_idx, frame_idx, auto_idx, B, C,
                        H, W, selec_reproj);
+    return launch_status();
+}
+
+
+// Tail of compute_losses (trainer.py:1092-1139).  sel, mask, target, multi, mono: [B][1][H][W] fp32; auto_idx int64 or NULL;
+// cons [B][H][W] fp32 or NULL; aug [B] fp32 or NULL; partial: workspace of ppea_loss_tail_blocks(B * H * W) * 3 floats;
+// out[0] = rl, out[1] = consistency loss (multi), out[2] = 1 / (sum(mask) + 1e-7).
+int ppea_loss_tail_blocks(long total) { return (int)((total + TAIL_TPB * TAIL_PER - 1) / (TAIL_TPB * TAIL_PER)); }
+int ppea_loss_tail_fwd_f32(const float* sel, const int64_t* auto_idx, const float* cons, const float* aug, const float* multi,
+                           const float* mono, float* mask, float* target, float* partial, float* out, int B, int H, int W,
+                           int is_multi, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return PPEA_ERR_UNSUPPORTED;
+    if (is_multi && (multi == nullptr || mono == nullptr || target == nullptr)) return PPEA_ERR_ARG;
+    const long hw = (long)H * W, total = (long)B * hw;
+    const int nblk = ppea_loss_tail_blocks(total);
+    hipLaunchKernelGGL(loss_tail_fwd, dim3(nblk), dim3(TAIL_TPB), 0, (hipStream_t)stream, sel, auto_idx, cons, aug, multi, mono,
+                       mask, target, partial, hw, total, is_multi);
+    hipLaunchKernelGGL(loss_tail_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblk, total, out);
+    return launch_status();
+}
+int ppea_loss_tail_bwd_f32(const float* mask, const uint8_t* src, const float* out, const float* g_rl, const float* g_con,
+                           const float* multi, const float* mono, float* d_reproj, float* d_multi, int B, int H, int W,
+                           void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return PPEA_ERR_UNSUPPORTED;
+    const long hw = (long)H * W, total = (long)B * hw;
+    hipLaunchKernelGGL(loss_tail_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mask, src, out,
+                       g_rl, g_con, multi, mono, d_reproj, d_multi, hw, total);
     return launch_status();
 }
 

@@ -160,6 +160,9 @@ SIGNATURES = {
     "ppea_nhwc_maxpool3x3s2_fwd_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_nhwc_maxpool3x3s2_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ppea_nhwc_maxpool3x3s2_bwd_bf16": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ppea_loss_tail_blocks": [_l],
+    "ppea_loss_tail_fwd_f32": [_vp] * 10 + [_i] * 4 + [_vp],
+    "ppea_loss_tail_bwd_f32": [_vp] * 9 + [_i] * 3 + [_vp],
     "ppea_cost_volume_fwd_bf16": [_vp] * 8 + [_i] * 5 + [_f, _vp],
     "ppea_cost_volume_reduce_f32": [_vp] * 6 + [_i] * 4 + [_vp],
 }

@@ -428,6 +428,53 @@ def loss_select(reproj, identity, warped_m1, warped_p1, noise, selec_reproj=True
     return _LossSelect.apply(reproj, identity, warped_m1, warped_p1, noise, selec_reproj)
 
 
+class _LossTail(torch.autograd.Function):
+    """Tail of compute_losses (trainer.py:1092-1139) in one pass per direction (csrc/photometric.hip loss_tail_*):
+    -> (rl, consistency_loss, mask, consistency_target).  `reproj` [B,2,H,W] is the differentiable input the selected loss
+    `sel` was taken from (`src`: which channel, 2 = forced zero); its gradient is produced directly."""
+
+    @staticmethod
+    def forward(ctx, reproj, sel, src, auto_idx, cons, aug, multi, mono, is_multi):
+        B, _, H, W = sel.shape
+        dev = sel.device
+        sel = sel.contiguous().float()
+        mask = torch.empty(B, 1, H, W, device=dev, dtype=_F32)
+        target = torch.empty(B, 1, H, W, device=dev, dtype=_F32) if is_multi else None
+        nblk = _abi.lib.ppea_loss_tail_blocks(B * H * W)
+        partial = torch.empty(nblk * 3, device=dev, dtype=_F32)
+        out = torch.empty(3, device=dev, dtype=_F32)
+        multi_c = None if multi is None else multi.detach().contiguous().float()
+        mono_c = None if mono is None else mono.detach().contiguous().float()
+        call("ppea_loss_tail_fwd_f32", ptr(sel), ptr(auto_idx), ptr(None if cons is None else cons.contiguous().float()),
+             ptr(None if aug is None else aug.reshape(-1).contiguous().float()), ptr(multi_c), ptr(mono_c), ptr(mask),
+             ptr(target), ptr(partial), ptr(out), B, H, W, int(bool(is_multi)), stream_ptr())
+        ctx.save_for_backward(mask, src, out, multi_c, mono_c)
+        ctx.dims = (B, H, W, bool(is_multi), multi is not None and multi.requires_grad)
+        ctx.set_materialize_grads(False)
+        rl, cl = out[0], out[1]
+        if target is not None:
+            ctx.mark_non_differentiable(mask, target)
+            return rl, cl, mask, target
+        ctx.mark_non_differentiable(mask)
+        return rl, cl, mask
+
+    @staticmethod
+    def backward(ctx, g_rl, g_cl, *_unused):
+        mask, src, out, multi, mono = ctx.saved_tensors
+        B, H, W, is_multi, multi_grad = ctx.dims
+        dev = mask.device
+        d_reproj = torch.empty(B, 2, H, W, device=dev, dtype=_F32) if ctx.needs_input_grad[0] else None
+        d_multi = torch.empty(B, 1, H, W, device=dev, dtype=_F32) if (is_multi and multi_grad and g_cl is not None) else None
+        call("ppea_loss_tail_bwd_f32", ptr(mask), ptr(src), ptr(out), ptr(None if g_rl is None else g_rl.contiguous().float()),
+             ptr(None if g_cl is None else g_cl.contiguous().float()), ptr(multi), ptr(mono), ptr(d_reproj), ptr(d_multi),
+             B, H, W, stream_ptr())
+        return d_reproj, None, None, None, None, None, d_multi, None, None
+
+
+def loss_tail(reproj, sel, src, auto_idx=None, cons=None, aug=None, multi=None, mono=None, is_multi=False):
+    return _LossTail.apply(reproj, sel, src, auto_idx, cons, aug, multi, mono, is_multi)
+
+
 # ---------------------------------------------------------------------------------------------
 # A9/A10  cost volume (runs under no_grad in the reference, rkm.py:427)
 # ---------------------------------------------------------------------------------------------

@@ -69,6 +69,9 @@ class DepthBins:
         return mn, mx
 
 
+FUSED_LOSS_TAIL = True      # compute_losses' mask / masked mean / consistency term on ops.loss_tail (HIP tensors)
+
+
 class _NullAccelerator:
     """The slice of `accelerate.Accelerator` that process_batch touches (trainer.py:436, 453, 465)."""
 
@@ -271,28 +274,42 @@ class Trainer:
                 reprojection_losses, identity_losses, outputs[("color", fids[0], scale)].detach(),
                 outputs[("color", fids[1], scale)].detach(), noise, opt.selec_reproj)
             outputs[("frame_idxs", scale)] = frame_idxs
-            if opt.disable_automasking:
-                mask = torch.ones_like(reprojection_loss)
-            else:
+            if not opt.disable_automasking:
                 outputs[("automask_idxs", scale)] = auto_idx
-                mask = (auto_idx == 0).float()
-            if is_multi:
-                mask = torch.ones_like(mask)
-                if not opt.disable_motion_masking:
-                    mask = mask * outputs["consistency_mask"].unsqueeze(1)
-                if not opt.no_matching_augmentation:
-                    mask = mask * (1 - outputs["augmentation_mask"][:B])
-                consistency_mask = (1 - mask).float()
-            rl = (reprojection_loss * mask).sum() / (mask.sum() + 1e-7)
-            if is_multi:
-                multi_depth = outputs[("depth", 0, scale)]
-                mono_depth = outputs[("mono_depth", 0, scale)].detach()
-                consistency_loss = (torch.abs(multi_depth - mono_depth) * consistency_mask).mean()
-                outputs["consistency_target/{}".format(scale)] = 1 / (
-                    mono_depth * consistency_mask + multi_depth.detach() * (1 - consistency_mask))
-                losses["consistency_loss/{}".format(scale)] = consistency_loss
+            if FUSED_LOSS_TAIL and reprojection_loss.is_cuda:
+                # mask, masked mean, consistency term and its target in one pass per direction (ops.loss_tail)
+                cons = outputs["consistency_mask"] if (is_multi and not opt.disable_motion_masking) else None
+                aug = outputs["augmentation_mask"][:B] if (is_multi and not opt.no_matching_augmentation) else None
+                res = ops.loss_tail(reprojection_losses, reprojection_loss.detach(), _src,
+                                    None if (opt.disable_automasking or is_multi) else auto_idx, cons, aug,
+                                    outputs[("depth", 0, scale)] if is_multi else None,
+                                    outputs[("mono_depth", 0, scale)] if is_multi else None, is_multi)
+                rl, consistency_loss = res[0], (res[1] if is_multi else 0)
+                if is_multi:
+                    outputs["consistency_target/{}".format(scale)] = res[3]
+                    losses["consistency_loss/{}".format(scale)] = consistency_loss
             else:
-                consistency_loss = 0
+                if opt.disable_automasking:
+                    mask = torch.ones_like(reprojection_loss)
+                else:
+                    mask = (auto_idx == 0).float()
+                if is_multi:
+                    mask = torch.ones_like(mask)
+                    if not opt.disable_motion_masking:
+                        mask = mask * outputs["consistency_mask"].unsqueeze(1)
+                    if not opt.no_matching_augmentation:
+                        mask = mask * (1 - outputs["augmentation_mask"][:B])
+                    consistency_mask = (1 - mask).float()
+                rl = (reprojection_loss * mask).sum() / (mask.sum() + 1e-7)
+                if is_multi:
+                    multi_depth = outputs[("depth", 0, scale)]
+                    mono_depth = outputs[("mono_depth", 0, scale)].detach()
+                    consistency_loss = (torch.abs(multi_depth - mono_depth) * consistency_mask).mean()
+                    outputs["consistency_target/{}".format(scale)] = 1 / (
+                        mono_depth * consistency_mask + multi_depth.detach() * (1 - consistency_mask))
+                    losses["consistency_loss/{}".format(scale)] = consistency_loss
+                else:
+                    consistency_loss = 0
             losses["reproj_loss/{}".format(scale)] = rl
             loss = rl + consistency_loss
             mean_disp = disp.mean(2, True).mean(3, True)

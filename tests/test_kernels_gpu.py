@@ -1724,3 +1724,49 @@ def test_maxpool3x3s2_nhwc_equals_torch(device, dtype, shape):
     else:       # torch accumulates the (up to four) bf16 contributions of a pixel in its own order; here: fp32 sum, one rounding
         assert rel_err(xd.grad.float().cpu(), xr.grad.float().cpu()) < 2 ** -7
         assert float((xd.grad != xr.grad).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("is_multi", [False, True])
+def test_loss_tail_equals_the_elementwise_composite(device, is_multi):
+    """ops.loss_tail (mask, masked mean of the selected reprojection loss, consistency term and target: trainer.py:1092-1139
+    in one pass per direction) against the reference's element-wise formulation in fp64 under autograd: both scalars, the
+    mask, the target, d reproj (routed by the selection's source index incl. the forced-zero code 2) and d multi_depth."""
+    from ppeadepth import ops
+    g = _g(5 + int(is_multi))
+    B, H, W = 3, 20, 36
+    reproj = torch.rand(B, 2, H, W, generator=g)
+    src = torch.randint(0, 3, (B, 1, H, W), generator=g).to(torch.uint8)
+    sel = torch.where(src == 0, reproj[:, :1], torch.where(src == 1, reproj[:, 1:], torch.zeros(B, 1, H, W)))
+    auto_idx = torch.randint(0, 2, (B, 1, H, W), generator=g)
+    cons = (torch.rand(B, H, W, generator=g) > 0.4).float()
+    aug = torch.tensor([0.0, 1.0, 0.0]).view(B, 1, 1, 1)
+    multi = 1 + torch.rand(B, 1, H, W, generator=g)
+    mono = 1 + torch.rand(B, 1, H, W, generator=g)
+    multi[0, 0, 0, :5] = mono[0, 0, 0, :5]                      # |.| at 0: gradient 0
+    # reference (fp64)
+    r = reproj.double().requires_grad_(True)
+    m64 = multi.double().requires_grad_(True)
+    selr = torch.where(src == 0, r[:, :1], torch.where(src == 1, r[:, 1:], torch.zeros(B, 1, H, W, dtype=torch.float64)))
+    if is_multi:
+        mask = cons.double().unsqueeze(1) * (1 - aug.double())
+    else:
+        mask = (auto_idx == 0).double()
+    rl_ref = (selr * mask).sum() / (mask.sum() + 1e-7)
+    cm = 1 - mask
+    cl_ref = (torch.abs(m64 - mono.double()) * cm).mean() if is_multi else None
+    tgt_ref = 1 / (mono.double() * cm + m64.detach() * (1 - cm)) if is_multi else None
+    (rl_ref * 0.7 + (cl_ref * 1.3 if is_multi else 0)).backward()
+    # kernels
+    rd = reproj.to(device).requires_grad_(True)
+    md = multi.to(device).requires_grad_(True)
+    res = ops.loss_tail(rd, sel.to(device), src.to(device), None if is_multi else auto_idx.to(device),
+                        cons.to(device) if is_multi else None, aug.to(device) if is_multi else None,
+                        md if is_multi else None, mono.to(device) if is_multi else None, is_multi)
+    (res[0] * 0.7 + (res[1] * 1.3 if is_multi else 0)).backward()
+    assert rel_err(res[0].detach().cpu().reshape(1), rl_ref.detach().reshape(1)) < 1e-6
+    assert torch.equal(res[2].cpu().double(), mask)
+    assert rel_err(rd.grad.cpu(), r.grad) < 1e-6
+    if is_multi:
+        assert rel_err(res[1].detach().cpu().reshape(1), cl_ref.detach().reshape(1)) < 1e-6
+        assert rel_err(res[3].cpu(), tgt_ref) < 1e-6
+        assert rel_err(md.grad.cpu(), m64.grad) < 1e-6
