@@ -21,6 +21,8 @@ from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
 
 def family(name):
+    if "at::" not in name and "rocclr" not in name and "Memcpy" not in name and "Memset" not in name:
+        return None                                       # this build's kernels (and RCCL)
     if "copyBuffer" in name or "Memcpy" in name:
         return "runtime copyBuffer"
     if "Memset" in name or "fillBuffer" in name:
