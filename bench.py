@@ -103,6 +103,21 @@ def cpu_baseline(seconds_budget=40.0, eval_root=None):
                      f"torch-CPU oracle, best of the non-first iterations ({best:.2f} s/step)"}
     if absrel_oracle is not None:
         out["absrel_oracle"] = absrel_oracle
+    # the REFERENCE's own CPU path (unmodified Trainer.process_batch + backward of /root/reference), timed in the build
+    # container by the committed harness tools/time_reference_cpu.py: the reference cannot travel to the GPU box, so its
+    # timing is quoted from the committed result file next to the port timed live on this host
+    ref_path = os.path.join(ROOT, "profiles", "r04_cpu_reference.json")
+    if os.path.exists(ref_path):
+        with open(ref_path) as f:
+            r = json.load(f)
+        out["reference_container"] = {
+            "file": "profiles/r04_cpu_reference.json (tools/time_reference_cpu.py)",
+            "host": f"{r['host']['nproc']} cores, torch {r['host']['torch']}, no GPU",
+            "img_per_s_8_threads": r["reference"]["threads_8"]["img_per_s"],
+            "s_per_step_8_threads": r["reference"]["threads_8"]["s_per_step_mean"],
+            "img_per_s_1_thread": r["reference"]["threads_1"]["img_per_s"],
+            "s_per_step_1_thread": r["reference"]["threads_1"]["s_per_step_mean"],
+            "port_img_per_s_8_threads_same_host": r["port"]["threads_8"]["img_per_s"]}
     return out
 
 
