@@ -169,6 +169,12 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)                # does not return
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when a communicator is created, and
+    # libraries may print more: from here on fd 1 is stderr, and the line is written to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from ppeadepth import dist as pdist
     from ppeadepth import networks, options, ops, rng
     from ppeadepth.trainer import Trainer
@@ -535,7 +541,8 @@ def main():
                     line["absrel"]["abs_diff_fp32"] = round(abs(line["absrel"]["fp32"] - line["absrel"]["oracle_cpu"]), 6)
             except Exception as ex:          # the baseline must never take the bench line down
                 line["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     if watchdog is not None:
         watchdog.start()
