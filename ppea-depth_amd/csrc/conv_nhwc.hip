@@ -61,9 +61,7 @@ struct ConvArgs {
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
 
 // BN output channels per workgroup; WM x WN waves; STRIDE and the (square) filter size KS compile time.
-// DB: both LDS images double buffered -- the next step's operands are stored into the other buffers before this step's
-// MFMAs and ONE barrier per step publishes them (single buffered: two barriers per step around the stores).
-template <int BN, int WM, int WN, int STRIDE, bool OUT_NCHW, int KS, bool DB = false>
+template <int BN, int WM, int WN, int STRIDE, bool OUT_NCHW, int KS>
 __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int MAX_A = (halo_cap(STRIDE, KS) * 4 + 255) / 256, MAX_B = (KS * BN * 4 + 255) / 256;
@@ -74,10 +72,8 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs a) {
     const int TR = a.TR, TC = a.TC;
     const int HALO_H = (TR - 1) * STRIDE + KS, HALO_W = (TC - 1) * STRIDE + KS;
     const int halo_px = HALO_H * HALO_W;
-    const int a_bytes = ((halo_px * PITCH + 127) / 128) * 128;
-    constexpr int b_bytes = KS * BN * PITCH;
     uint8_t* ldsA = lds;
-    uint8_t* ldsB = lds + (DB ? 2 : 1) * a_bytes;
+    uint8_t* ldsB = lds + ((halo_px * PITCH + 127) / 128) * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -133,11 +129,11 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs a) {
             }
         }
     };
-    auto store_a = [&](uint8_t* dstA) {
+    auto store_a = [&]() {
 #pragma unroll
         for (int c = 0; c < MAX_A; ++c) {
             const int q = tid + c * 256;
-            if (q < a_chunks) *reinterpret_cast<uint4*>(dstA + (q >> 2) * PITCH + (((q & 3) ^ swz_chunk(q >> 2)) << 4)) = a_reg[c];
+            if (q < a_chunks) *reinterpret_cast<uint4*>(ldsA + (q >> 2) * PITCH + (((q & 3) ^ swz_chunk(q >> 2)) << 4)) = a_reg[c];
         }
     };
     auto load_b = [&](int c0, int r) {
@@ -153,11 +149,11 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs a) {
             }
         }
     };
-    auto store_b = [&](uint8_t* dstB) {
+    auto store_b = [&]() {
 #pragma unroll
         for (int c = 0; c < MAX_B; ++c) {
             const int q = tid + c * 256;
-            if (q < b_chunks) *reinterpret_cast<uint4*>(dstB + (q >> 2) * PITCH + (((q & 3) ^ swz_chunk(q >> 2)) << 4)) = b_reg[c];
+            if (q < b_chunks) *reinterpret_cast<uint4*>(ldsB + (q >> 2) * PITCH + (((q & 3) ^ swz_chunk(q >> 2)) << 4)) = b_reg[c];
         }
     };
 
@@ -174,18 +170,30 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs a) {
 
     // ---- main loop over (channel slice, filter row): registers hold the NEXT step's operands while this one computes ----
     const int steps = (a.CinP / 32) * KS;
-    auto compute = [&](const uint8_t* curA, const uint8_t* curB, int r) {
+    load_a(0);
+    load_b(0, 0);
+    for (int st = 0; st < steps; ++st) {
+        const int r = st % KS;
+        __syncthreads();                                       // every wave is done with the previous step's LDS image
+        store_b();
+        if (r == 0) store_a();
+        __syncthreads();
+        const int nxt = st + 1;
+        if (nxt < steps) {
+            load_b((nxt / KS) * 32, nxt % KS);
+            if ((nxt % KS) == 0) load_a((nxt / KS) * 32);
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             bf16x8 af[MT], bfr[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int px = a_px[i] + r * HALO_W + s;
-                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(curA + px * PITCH + ((g ^ swz_chunk(px)) << 4)));
+                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ldsA + px * PITCH + ((g ^ swz_chunk(px)) << 4)));
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(curB + b_off + (s * BN + j * 16) * PITCH));
+                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ldsB + b_off + (s * BN + j * 16) * PITCH));
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -195,47 +203,6 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs a) {
                     else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
                 }
-        }
-    };
-    load_a(0);
-    load_b(0, 0);
-    if constexpr (DB) {
-        store_b(ldsB);
-        store_a(ldsA);
-        if (steps > 1) {
-            load_b((1 / KS) * 32, 1 % KS);
-            if ((1 % KS) == 0) load_a((1 / KS) * 32);
-        }
-        __syncthreads();
-        for (int st = 0; st < steps; ++st) {
-            const int r = st % KS, nxt = st + 1;
-            // the registers hold step nxt's operands (loaded one compute phase ago): publish them in the OTHER buffers --
-            // every wave has passed the barrier behind step st - 1, the last reader of those buffers
-            if (nxt < steps) {
-                store_b(ldsB + (nxt & 1) * b_bytes);
-                if ((nxt % KS) == 0) store_a(ldsA + ((nxt / KS) & 1) * a_bytes);
-                const int n2 = st + 2;
-                if (n2 < steps) {
-                    load_b((n2 / KS) * 32, n2 % KS);
-                    if ((n2 % KS) == 0) load_a((n2 / KS) * 32);
-                }
-            }
-            compute(ldsA + ((st / KS) & 1) * a_bytes, ldsB + (st & 1) * b_bytes, r);
-            __syncthreads();
-        }
-    } else {
-        for (int st = 0; st < steps; ++st) {
-            const int r = st % KS;
-            __syncthreads();                                       // every wave is done with the previous step's LDS image
-            store_b(ldsB);
-            if (r == 0) store_a(ldsA);
-            __syncthreads();
-            const int nxt = st + 1;
-            if (nxt < steps) {
-                load_b((nxt / KS) * 32, nxt % KS);
-                if ((nxt % KS) == 0) load_a((nxt / KS) * 32);
-            }
-            compute(ldsA, ldsB, r);
         }
     }
 
@@ -313,17 +280,13 @@ void pick_tile(ConvArgs& a, int stride, int ks, bool nchw) {
     a.tiles_x = (a.Wo + a.TC - 1) / a.TC; a.tiles_y = (a.Ho + a.TR - 1) / a.TR;
 }
 
-template <int BN, int WM, int WN, int STRIDE, bool NCHW, int KS, bool DB = false>
+template <int BN, int WM, int WN, int STRIDE, bool NCHW, int KS>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     const int halo_px = ((a.TR - 1) * STRIDE + KS) * ((a.TC - 1) * STRIDE + KS);
     if (halo_px > halo_cap(STRIDE, KS)) return PPEA_ERR_UNSUPPORTED;
-    if constexpr (!DB && KS == 3) {
-        static const bool want_db = getenv("PPEA_CONV_DB") != nullptr && getenv("PPEA_CONV_DB")[0] == '1';
-        if (want_db) return launch_conv<BN, WM, WN, STRIDE, NCHW, KS, true>(a, st);
-    }
-    const size_t smem = (DB ? 2 : 1) * ((size_t)((halo_px * PITCH + 127) / 128) * 128 + (size_t)KS * BN * PITCH);
+    const size_t smem = (size_t)((halo_px * PITCH + 127) / 128) * 128 + (size_t)KS * BN * PITCH;
     if (smem > 160 * 1024) return PPEA_ERR_UNSUPPORTED;
-    auto kern = conv_nhwc_kernel<BN, WM, WN, STRIDE, NCHW, KS, DB>;
+    auto kern = conv_nhwc_kernel<BN, WM, WN, STRIDE, NCHW, KS>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
