@@ -61,10 +61,13 @@ struct ConvArgs {
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_ELU = 2, ACT_SIGMOID = 3 };
 
 // BN output channels per workgroup; WM x WN waves; STRIDE and the (square) filter size KS compile time.
-template <int BN, int WM, int WN, int STRIDE, bool OUT_NCHW, int KS>
+// RPS: filter rows whose weights are staged per step (1: one row -- two barriers per row; KS: the whole K x K slice at once --
+// two barriers per 32-channel slice, K x the weight bytes in LDS).
+template <int BN, int WM, int WN, int STRIDE, bool OUT_NCHW, int KS, int RPS = 1>
 __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "four waves");
-    constexpr int MAX_A = (halo_cap(STRIDE, KS) * 4 + 255) / 256, MAX_B = (KS * BN * 4 + 255) / 256;
+    static_assert(RPS == 1 || RPS == KS, "one filter row or all of them per step");
+    constexpr int MAX_A = (halo_cap(STRIDE, KS) * 4 + 255) / 256, MAX_B = (RPS * KS * BN * 4 + 255) / 256;
     constexpr int MT = 8 / WM;             // 16-pixel M tiles per wave
     constexpr int NT = BN / 16 / WN;       // 16-channel column tiles per wave
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs a) {
             if (ok) a_src[c] = ((ih / a.dil) * a.W + iw / a.dil) * a.Cin + (q & 3) * 8;      // < 2^31 per image
         }
     }
-    constexpr int b_chunks = KS * BN * 4;
+    constexpr int b_chunks = RPS * KS * BN * 4;
     uint4 a_reg[MAX_A], b_reg[MAX_B];
 
     auto load_a = [&](int c0) {
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs a) {
         for (int c = 0; c < MAX_B; ++c) {
             const int q = tid + c * 256;
             if (q < b_chunks) {
-                const int row = q >> 2;                       // s * BN + column
+                const int row = q >> 2;                       // (rr * KS + s) * BN + column; rr = 0 for one row per step
                 const int s = row / BN, co = co0 + row % BN;
                 b_reg[c] = co < a.Cout ? *reinterpret_cast<const uint4*>(
                                              a.w + ((long)(r * KS + s) * a.Cout + co) * a.CinP + c0 + (q & 3) * 8)
@@ -169,40 +172,45 @@ __global__ __launch_bounds__(256, 2) void conv_nhwc_kernel(const ConvArgs a) {
     const int b_off = (wn * NT * 16 + li) * PITCH + ((g ^ swz_chunk(li)) << 4);
 
     // ---- main loop over (channel slice, filter row): registers hold the NEXT step's operands while this one computes ----
-    const int steps = (a.CinP / 32) * KS;
+    constexpr int SPS = KS / RPS;                              // steps per channel slice
+    const int steps = (a.CinP / 32) * SPS;
     load_a(0);
     load_b(0, 0);
     for (int st = 0; st < steps; ++st) {
-        const int r = st % KS;
+        const int r0 = (st % SPS) * RPS;                       // first filter row of this step
         __syncthreads();                                       // every wave is done with the previous step's LDS image
         store_b();
-        if (r == 0) store_a();
+        if (r0 == 0) store_a();
         __syncthreads();
         const int nxt = st + 1;
         if (nxt < steps) {
-            load_b((nxt / KS) * 32, nxt % KS);
-            if ((nxt % KS) == 0) load_a((nxt / KS) * 32);
+            load_b((nxt / SPS) * 32, (nxt % SPS) * RPS);
+            if ((nxt % SPS) == 0) load_a((nxt / SPS) * 32);
         }
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            bf16x8 af[MT], bfr[NT];
+        for (int rr = 0; rr < RPS; ++rr) {
+            const int r = r0 + rr;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int px = a_px[i] + r * HALO_W + s;
-                af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ldsA + px * PITCH + ((g ^ swz_chunk(px)) << 4)));
-            }
+            for (int s = 0; s < KS; ++s) {
+                bf16x8 af[MT], bfr[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ldsB + b_off + (s * BN + j * 16) * PITCH));
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if constexpr (OUT_NCHW)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                    else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MT; ++i) {
+                    const int px = a_px[i] + r * HALO_W + s;
+                    af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ldsA + px * PITCH + ((g ^ swz_chunk(px)) << 4)));
                 }
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    bfr[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ldsB + b_off + ((rr * KS + s) * BN + j * 16) * PITCH));
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        if constexpr (OUT_NCHW)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    }
+            }
         }
     }
 
@@ -280,13 +288,22 @@ void pick_tile(ConvArgs& a, int stride, int ks, bool nchw) {
     a.tiles_x = (a.Wo + a.TC - 1) / a.TC; a.tiles_y = (a.Ho + a.TR - 1) / a.TR;
 }
 
-template <int BN, int WM, int WN, int STRIDE, bool NCHW, int KS>
+template <int BN, int WM, int WN, int STRIDE, bool NCHW, int KS, int RPS = 1>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     const int halo_px = ((a.TR - 1) * STRIDE + KS) * ((a.TC - 1) * STRIDE + KS);
     if (halo_px > halo_cap(STRIDE, KS)) return PPEA_ERR_UNSUPPORTED;
-    const size_t smem = (size_t)((halo_px * PITCH + 127) / 128) * 128 + (size_t)KS * BN * PITCH;
+    if constexpr (RPS == 1 && KS == 3 && BN <= 64) {
+        // Long contractions (>= 256 input channels): the whole 3 x 3 weight slice per step -- 2 barriers per 32-channel slice
+        // instead of 6; the waves of these layers were parked at barriers for 35-50 % of their cycles (PMC, round 2).
+        // 1024 -> 512 @6x20 forward 106 -> 59 us, @12x40 161 -> 107, ResNet 512 -> 512 55 -> 38 / data gradient 42 -> 29
+        // (profiles/r04_conv_layers_vs_library.txt).  With 64 / 128 input channels the 36 KB weight image per 12-17 KB
+        // halo costs occupancy and loses (64 -> 64 @96x320: 74 -> 95 us): those keep one filter row per step.
+        static const bool one_row = getenv("PPEA_CONV_RPS") != nullptr && getenv("PPEA_CONV_RPS")[0] == '1';
+        if (!one_row && a.CinP >= 256) return launch_conv<BN, WM, WN, STRIDE, NCHW, KS, KS>(a, st);
+    }
+    const size_t smem = (size_t)((halo_px * PITCH + 127) / 128) * 128 + (size_t)RPS * KS * BN * PITCH;
     if (smem > 160 * 1024) return PPEA_ERR_UNSUPPORTED;
-    auto kern = conv_nhwc_kernel<BN, WM, WN, STRIDE, NCHW, KS>;
+    auto kern = conv_nhwc_kernel<BN, WM, WN, STRIDE, NCHW, KS, RPS>;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
