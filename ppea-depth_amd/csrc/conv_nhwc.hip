@@ -318,7 +318,10 @@ int dispatch_bn(const ConvArgs& a, hipStream_t st) {
     const long tiles = (long)a.tiles_x * a.tiles_y * a.N;
     if constexpr (KS <= 3) {
         // 128 channels per workgroup only when that still leaves two waves of workgroups for the 256 CUs
-        if (a.Cout > 64 && tiles * ((a.Cout + 127) / 128) >= 512) return launch_conv<128, 2, 2, STRIDE, NCHW, KS>(a, st);
+        // (3 x 3 with >= 256 input channels: 64 channels per workgroup with the whole weight slice per step is faster than
+        // 128 with one filter row per step -- 256 -> 128 @48x160 forward 105 -> 97 us; launch_conv)
+        if (a.Cout > 64 && tiles * ((a.Cout + 127) / 128) >= 512 && !(KS == 3 && a.CinP >= 256))
+            return launch_conv<128, 2, 2, STRIDE, NCHW, KS>(a, st);
     }
     // 64 channels per workgroup unless that leaves CUs without one (small maps, e.g. 1024 -> 512 @6x20: 96 workgroups)
     static const bool no_narrow = getenv("PPEA_CONV_NO_NARROW") != nullptr;           // tuning hook (tools/bench_conv.py)
