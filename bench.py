@@ -353,7 +353,7 @@ def main():
                    "bound": "mfma", "achieved": round(flops / t_pw / 1e12, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                    "frac": round(flops / t_pw / 1e12 / MFMA_BF16_PEAK_TF, 4), "traffic": None,
                    "back_to_back_us": round(t_pw * 1e6, 1), "flops_per_launch": flops,
-                   "note": "host-paced launches; hipGraph-paced per trunk shape vs the library: profiles/r03_pwconv_shapes.txt; "
+                   "note": "host-paced launches; hipGraph-paced per trunk shape vs the library: profiles/r04_pwconv_shapes.txt; "
                            "algorithmic bytes %.1f MB" % ((B * 480 * (512 + 2048) + 512 * 2048) * 2 / 1e6)}
         del xx, aa
     barrier()
