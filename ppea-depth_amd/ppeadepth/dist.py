@@ -285,6 +285,7 @@ class FlatGrads:
 FLAT_ADAM = True     # one-launch Adam over a flat parameter buffer (GPU, fused path)
 # several ranks: chunked gradient all-reduce launched from autograd hooks during backward (PPEA_OVERLAP=0: after it)
 OVERLAP_ALLREDUCE = os.environ.get("PPEA_OVERLAP", "1") == "1"
+N1_RANGE_HOOKS = os.environ.get("PPEA_N1_HOOKS", "1") == "1"     # one rank: pack gradient ranges from the hooks too
 
 
 # Branches of the step's backward pass, in the order they finish (networks/repdepth.py forks the teacher onto a side
@@ -313,13 +314,17 @@ class TrainEngine:
         self.params = [p for p in model.parameters() if p.requires_grad]
         # reverse registration order ~ the order in which backward finishes the gradients
         self.params = list(reversed(self.params))
-        if collectives_on() and OVERLAP_ALLREDUCE:
+        on_gpu = self.params[0].is_cuda
+        # One rank: the same hooks pack each branch's gradients into the flat buffer on the stream that produced them (the
+        # teacher's and the adapters' multi-tensor copies then run beside the student's backward instead of after it).
+        self.range_hooks = (collectives_on() and OVERLAP_ALLREDUCE) or (N1_RANGE_HOOKS and on_gpu and FLAT_ADAM
+                                                                         and (fused_adam is None or fused_adam))
+        if self.range_hooks:
             # tensors of one backward branch sit together (stable sort: reverse registration order inside a branch)
             names = {id(p): n for n, p in model.named_parameters()}
             rank_of = {b: i for i, b in enumerate(_BRANCH_ORDER)}
             self.params.sort(key=lambda p: rank_of[_branch_of(names[id(p)])])
         lr = trainer.opt.learning_rate if lr is None else lr
-        on_gpu = self.params[0].is_cuda
         if fused_adam is None:
             fused_adam = on_gpu
         # the tensors Adam updates: the fp32 master of a bf16 parameter, else the parameter itself
@@ -346,7 +351,7 @@ class TrainEngine:
             # gradients (logging, clipping, export) use `mean_grads()`.
             self.flat.scale_in_optimizer = True
             self.grad_scale = 1.0 / world_size()
-        if self.flat is not None and collectives_on() and OVERLAP_ALLREDUCE:
+        if self.flat is not None and self.range_hooks:
             # gradient exchange overlapped with backward, one range per (branch of the step, dtype class)
             names = {id(p): n for n, p in model.named_parameters()}
             self.flat.install_hooks(self.params, [_branch_of(names[id(p)]) for p in self.params])

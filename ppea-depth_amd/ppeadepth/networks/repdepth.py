@@ -6,12 +6,14 @@ reference's.  Host-side differences: no per-item `.sum() == 0` device syncs (don
 the matching augmentation is applied with batched index ops, and BN bookkeeping of the whole
 forward is flushed in a handful of multi-tensor kernels.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import rng
+from .. import ops, rng
 from ..batchnorm import DeferredStats, set_deferred
 from ..layers import transformation_from_parameters
 from .depth_decoder_v2 import DepthDecoderV2
@@ -24,6 +26,7 @@ _ENC_CH = {"b": [128, 256, 512, 1024], "l": [192, 384, 768, 1536]}
 
 
 TWO_STREAMS = True
+ASYNC_FLUSH = os.environ.get("PPEA_ASYNC_FLUSH", "1") == "1"   # deferred running-statistics update beside the loss
 BATCHED_POSES = True      # third (no_grad) pose pass replayed instead of recomputed (see _predict_poses_batched)
 POSE_ONE_BATCH = True      # both pairs as one 2B batch with per-pair BN statistics (needs the fused NHWC BN path)
 
@@ -82,6 +85,8 @@ class RepDepth(nn.Module):
         self.freeze_pose = False
         self.dc = dc
         self._bn_book = DeferredStats()
+        self.defer_flush_join = False      # set by a caller that calls join_flush() itself (Trainer.process_batch)
+        self.pending_flush = None
 
     # repdepth.py:47-66, 121-140
     def _apply_freeze_rule(self, module, keep):
@@ -293,5 +298,21 @@ class RepDepth(nn.Module):
         finally:
             set_deferred(None)
             if book is not None:
-                book.flush()
+                main = torch.cuda.current_stream() if torch.cuda.is_available() else None
+                if ASYNC_FLUSH and self.defer_flush_join and main is not None and next(self.parameters()).is_cuda:
+                    # nothing reads the running statistics before the next step: the ~45 multi-tensor launches go to the
+                    # side stream, beside the loss; the caller (Trainer.process_batch) joins it
+                    side = ops.side_stream_of(main)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        book.flush()
+                    self.pending_flush = side
+                else:
+                    book.flush()
         return mono_outputs, outputs
+
+    def join_flush(self):
+        """Order the current stream after a running-statistics update that `forward` left on the side stream."""
+        side, self.pending_flush = self.pending_flush, None
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)

@@ -116,11 +116,16 @@ class Trainer:
             # too: no host-side `updated` branch, which a captured step graph would freeze at capture time.
             min_depth, max_depth = tracker.compute()
         self._identity_cache = None
-        if self.amp_dtype is not None:
-            with torch.autocast("cuda", dtype=self.amp_dtype):
+        module = self._module()
+        module.defer_flush_join = True           # joined below, after the losses
+        try:
+            if self.amp_dtype is not None:
+                with torch.autocast("cuda", dtype=self.amp_dtype):
+                    mono_outputs, outputs = self.model(inputs, min_depth, max_depth)
+            else:
                 mono_outputs, outputs = self.model(inputs, min_depth, max_depth)
-        else:
-            mono_outputs, outputs = self.model(inputs, min_depth, max_depth)
+        finally:
+            module.defer_flush_join = False
 
         self.generate_images_pred(inputs, mono_outputs)
         mono_losses, _ = self.compute_losses(inputs, mono_outputs, is_multi=False)
@@ -139,6 +144,7 @@ class Trainer:
         if not self.freeze_tp and not getattr(self.opt, "notadabins", False):
             self.acc.wait_for_everyone()
             tracker.update(outputs[("mono_depth", 0, 0)])
+        module.join_flush()
         return outputs, losses
 
     # ---- trainer.py:653-857 -----------------------------------------------------------------------
