@@ -29,6 +29,11 @@ extern "C" {
 /* Library / build identification: returns the ABI version (bumped on any signature change). */
 int ppea_abi_version(void);
 
+/* Measurement aid (tools/step_timeline.py): a one-lane launch on `stream` that writes the device's constant-rate clock
+ * (wall_clock64, 100 MHz) to *slot (uint64, device memory) -- a timestamp of that point of the stream that also works inside
+ * a captured graph, where HIP events cannot be timed. */
+int ppea_timestamp(void* slot, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * A1  Large-kernel depthwise convolution  (networks/replknet_adapter.py:151-168 get_conv2d,
  *     :232-239 ReparamLargeKernelConv.forward).  stride 1, pad K/2, dilation 1, no bias.

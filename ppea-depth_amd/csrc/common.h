@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define PPEA_ABI_VERSION 11
+#define PPEA_ABI_VERSION 12
 #define PPEA_ERR_UNSUPPORTED (-1)
 #define PPEA_ERR_ARG (-2)
 #define WAVE 64

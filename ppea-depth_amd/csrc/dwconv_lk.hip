@@ -346,11 +346,20 @@ int bwd_impl(const T* dyb, const T* dys, const float* wb, const float* ws, T* dx
     return r;
 }
 
+// measurement aid: one lane writes the constant-rate device clock (s_memrealtime, 100 MHz) to *slot
+__global__ void timestamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+
 }  // namespace
 
 extern "C" {
 
 int ppea_abi_version(void) { return PPEA_ABI_VERSION; }
+
+int ppea_timestamp(void* slot, void* stream) {
+    if (slot == nullptr) return PPEA_ERR_ARG;
+    hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)slot);
+    return launch_status();
+}
 
 int ppea_dwconv_lk_fwd_f32(const float* x, const float* w_big, const float* w_small, float* y_big,
                            float* y_small, int N, int C, int H, int W, int K, int KS, void* stream) {

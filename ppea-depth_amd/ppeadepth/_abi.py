@@ -12,13 +12,14 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libppea_depth.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 # name -> argtypes (restype is always int = hipError_t); mirrors include/ppea_depth.h
 SIGNATURES = {
     "ppea_abi_version": [],
+    "ppea_timestamp": [_vp, _vp],
     "ppea_dwconv_lk_fwd_f32": [_vp] * 5 + [_i] * 6 + [_vp],
     "ppea_dwconv_lk_fwd_bf16": [_vp] * 5 + [_i] * 6 + [_vp],
     "ppea_dwconv_lk_bwd_data_f32": [_vp] * 5 + [_i] * 6 + [_vp],

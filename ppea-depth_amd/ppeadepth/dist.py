@@ -54,6 +54,8 @@ def init_distributed(backend=None):
 COMM = {}
 _COMM_OF_BRANCH = {"depth": "encoder", "encoder": "encoder", "pose": "encoder", "mono_depth": "mono_encoder",
                    "mono_encoder": "mono_encoder", "encoder_adapters": "adapters"}
+if os.environ.get("PPEA_POSE_SIDE", "1") == "1":      # networks/repdepth.py POSE_SIDE: the pose network lives on the adapter stream
+    _COMM_OF_BRANCH["pose"] = "adapters"
 _KEY_OF = {}              # id(process group) -> communicator key ("encoder" / "mono_encoder" / "adapters"); else "world"
 
 # Tests / bench.py: while this is a list, every collective the step issues appends (communicator key, op, elements,
@@ -293,11 +295,16 @@ N1_RANGE_HOOKS = os.environ.get("PPEA_N1_HOOKS", "1") == "1"     # one rank: pac
 _BRANCH_ORDER = ("depth", "mono_depth", "encoder_adapters", "encoder", "mono_encoder", "pose")
 
 
+_STAGE0_INLINE = os.environ.get("PPEA_POSE_SIDE", "1") == "1" and os.environ.get("PPEA_POSE_SIDE_INLINE0", "1") == "1"
+
+
 def _branch_of(name):
     top = name.split(".")[0]
     if top in ("mono_depth", "mono_encoder", "depth"):
         return top
     if top == "encoder":
+        if _STAGE0_INLINE and name.startswith("encoder.replk.stages.0."):
+            return "encoder"     # (networks/repdepth.py POSE_SIDE: the student's stage-0 adapters run on the step stream)
         return "encoder_adapters" if (".adapter." in name or ".mlp_adapter." in name) else "encoder"
     return "pose"            # pose_encoder, pose (and anything else: launched after backward if streams mix)
 

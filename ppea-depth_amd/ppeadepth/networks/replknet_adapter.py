@@ -411,6 +411,7 @@ class ConvFFN(nn.Module):
     def __init__(self, in_channels, internal_channels, out_channels, drop_path, gamma=1.0, adpt_test=0,
                  ratio=0.25):
         super().__init__()
+        self.inline_adapter = False        # True: the adapter runs on the block's own stream (RepDepth: stage 0 with POSE_SIDE)
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
         self.preffn_bn = get_bn(in_channels)
         self.pw1 = conv_bn(in_channels, internal_channels, 1, 1, 0, 1)
@@ -432,7 +433,7 @@ class ConvFFN(nn.Module):
                 out, x = fused_bn_act(x, self.preffn_bn, skip=True)    # x: the same tensor, routed for the residual use
             adpt, join = None, None
             if self.test_id >= 0:
-                if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
+                if ADAPTER_STREAMS and not self.inline_adapter and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
                     adpt, join = _forked_adapter(self.mlp_adapter, second_use(out) if BN_DUP_FORKED else out)
                 else:
                     # hand the adapter the alias of `out` whose gradient joins pw1's inside the BatchNorm's backward launch
@@ -465,6 +466,7 @@ class RepLKBlock(nn.Module):
     def __init__(self, in_channels, dw_channels, block_lk_size, small_kernel, drop_path, gamma=1.0,
                  small_kernel_merged=False, adpt_test=0, ratio=0.25):
         super().__init__()
+        self.inline_adapter = False        # True: the adapter runs on the block's own stream (RepDepth: stage 0 with POSE_SIDE)
         self.pw1 = conv_bn_relu(in_channels, dw_channels, 1, 1, 0, 1)
         self.pw2 = conv_bn(dw_channels, in_channels, 1, 1, 0, 1)
         self.large_kernel = ReparamLargeKernelConv(dw_channels, dw_channels, block_lk_size, 1, dw_channels,
@@ -515,7 +517,7 @@ class RepLKBlock(nn.Module):
                 out, x = fused_bn_act(x, self.prelkb_bn, skip=True)    # x: the same tensor, routed for the residual use
             adpt, join = None, None
             if self.test_id >= 0:
-                if ADAPTER_STREAMS and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
+                if ADAPTER_STREAMS and not self.inline_adapter and torch.cuda.current_stream().cuda_stream not in NO_FORK_ON:
                     adpt, join = _forked_adapter(self.adapter, second_use(out) if BN_DUP_FORKED else out)
                 else:
                     adpt = self.adapter(second_use(out))         # (see ConvFFN.forward)

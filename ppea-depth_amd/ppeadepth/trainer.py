@@ -11,6 +11,7 @@ What changed on the way to the MI355X:
   * data-parallel gradient exchange is one flat RCCL all-reduce (see dist.py).
 """
 import contextlib
+import os
 
 import torch
 import torch.nn.functional as F
@@ -69,6 +70,7 @@ class DepthBins:
         return mn, mx
 
 
+MONO_LOSS_SIDE = os.environ.get("PPEA_MONO_SIDE", "1") == "1"   # the teacher's loss on the side stream, beside the student's
 FUSED_LOSS_TAIL = True      # compute_losses' mask / masked mean / consistency term on ops.loss_tail (HIP tensors)
 
 
@@ -127,8 +129,24 @@ class Trainer:
         finally:
             module.defer_flush_join = False
 
-        self.generate_images_pred(inputs, mono_outputs)
-        mono_losses, _ = self.compute_losses(inputs, mono_outputs, is_multi=False)
+        side = module.pending_flush if (MONO_LOSS_SIDE and not self.freeze_tp) else None
+        if side is not None:
+            # The teacher's loss needs nothing of the student and the student's loss needs only the teacher's depth and the
+            # identity terms: those two are computed here, the rest of the teacher's loss goes to the side stream (idle at this
+            # point of the step, already forked for the running-statistics update) and is joined where the two losses are summed.
+            main = torch.cuda.current_stream()
+            self.generate_images_pred(inputs, mono_outputs, depth_only=True)
+            self._identity_losses(inputs)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.generate_images_pred(inputs, mono_outputs, skip_depth=True)
+                mono_losses, _ = self.compute_losses(inputs, mono_outputs, is_multi=False)
+                for v in mono_losses.values():
+                    if torch.is_tensor(v):
+                        v.record_stream(main)
+        else:
+            self.generate_images_pred(inputs, mono_outputs)
+            mono_losses, _ = self.compute_losses(inputs, mono_outputs, is_multi=False)
 
         for key in list(mono_outputs.keys()):
             if key[0] in ("depth", "disp"):
@@ -138,6 +156,8 @@ class Trainer:
         self.generate_images_pred(inputs, outputs, is_multi=True)
         losses, _ = self.compute_losses(inputs, outputs, is_multi=True)
 
+        if side is not None:
+            module.join_flush()
         if not self.freeze_tp:
             for key, val in mono_losses.items():
                 losses[key] = losses[key] + val
@@ -218,14 +238,19 @@ class Trainer:
         return mask[:, 0]
 
     # ---- trainer.py:871-919 -----------------------------------------------------------------------
-    def generate_images_pred(self, inputs, outputs, is_multi=False):
+    def generate_images_pred(self, inputs, outputs, is_multi=False, depth_only=False, skip_depth=False):
         opt = self.opt
         for scale in range(opt.sclm + 1):
-            disp = outputs[("disp", scale)].float()
-            if disp.shape[-2:] != (opt.height, opt.width):
-                disp = F.interpolate(disp, [opt.height, opt.width], mode="bilinear", align_corners=False)
-            _, depth = disp_to_depth(disp, opt.min_depth, opt.max_depth)
-            outputs[("depth", 0, scale)] = depth
+            if skip_depth:
+                depth = outputs[("depth", 0, scale)]
+            else:
+                disp = outputs[("disp", scale)].float()
+                if disp.shape[-2:] != (opt.height, opt.width):
+                    disp = F.interpolate(disp, [opt.height, opt.width], mode="bilinear", align_corners=False)
+                _, depth = disp_to_depth(disp, opt.min_depth, opt.max_depth)
+                outputs[("depth", 0, scale)] = depth
+            if depth_only:
+                continue
             for frame_id in opt.frame_ids[1:]:
                 T = outputs[("cam_T_cam", 0, frame_id)].float()
                 if is_multi:
