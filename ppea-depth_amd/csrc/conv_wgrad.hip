@@ -84,6 +84,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
 
     const int x_chunks = halo_px * XCH;
     uint4 z_reg[MAX_Z], x_reg[MAX_X];
+    // (row, column) of every staged chunk inside the patch: the same for every patch of the loop below -- the divisions by the
+    // run-time tile shape are done once, not per patch (they were a third of the loop: 13 chunks x 3 divisions per thread)
+    // (the 32 x 32 tile and the stride-2 instantiations keep the in-loop form: with the tables they sit at the 256-VGPR limit
+    // and ran slower -- 32 -> 32 @192x640 98 -> 124 us, the three stride-2 ResNet layers 45 / 51 / 43 -> 55 / 62 / 52)
+    constexpr bool HOIST = STRIDE == 1 && !(BM == 32 && BN == 32);
+    int z_rc[HOIST ? MAX_Z : 1], x_rc[HOIST ? MAX_X : 1];
+    auto rc_of = [&](int px, int width) { return ((px / width) << 16) | (px % width); };
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int c = 0; c < MAX_Z; ++c) {
+            const int px = (tid + c * 256) / ZCH;
+            z_rc[c] = px < TR * TC ? rc_of(px, TC) : -1;
+        }
+#pragma unroll
+        for (int c = 0; c < MAX_X; ++c) {
+            const int idx = tid + c * 256;
+            x_rc[c] = idx < x_chunks ? rc_of(idx / XCH, HALO_W) : -1;
+        }
+    }
 
     auto load_patch = [&](int patch) {
         int t = patch;
@@ -95,9 +114,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
         const uint16_t* xn = a.x + (long)n * a.H * a.W * a.Cin;
 #pragma unroll
         for (int c = 0; c < MAX_Z; ++c) {
-            const int idx = tid + c * 256, px = idx / ZCH, ch = co0 + (idx % ZCH) * 8;
-            const int oh = oh0 + px / TC, ow = ow0 + px % TC;
-            z_reg[c] = (px < TR * TC && oh < a.Ho && ow < a.Wo && ch < a.Cout)
+            const int idx = tid + c * 256, ch = co0 + (idx % ZCH) * 8;
+            int oh, ow;
+            bool in_tile;
+            if constexpr (HOIST) {
+                in_tile = z_rc[c] >= 0;
+                oh = oh0 + (z_rc[c] >> 16); ow = ow0 + (z_rc[c] & 0xffff);
+            } else {
+                const int px = idx / ZCH;
+                in_tile = px < TR * TC;
+                oh = oh0 + px / TC; ow = ow0 + px % TC;
+            }
+            z_reg[c] = (in_tile && oh < a.Ho && ow < a.Wo && ch < a.Cout)
                            ? *reinterpret_cast<const uint4*>(zn + ((long)oh * a.Wo + ow) * a.Cout + ch) : make_uint4(0, 0, 0, 0);
         }
         const int ih0 = oh0 * STRIDE - a.pad, iw0 = ow0 * STRIDE - a.pad;
@@ -105,8 +133,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
         for (int c = 0; c < MAX_X; ++c) {
             const int idx = tid + c * 256;
             if (idx < x_chunks) {
-                const int px = idx / XCH, ch = ci0 + (idx % XCH) * 8;
-                int ih = ih0 + px / HALO_W, iw = iw0 + px % HALO_W;
+                const int ch = ci0 + (idx % XCH) * 8;
+                int ih, iw;
+                if constexpr (HOIST) {
+                    ih = ih0 + (x_rc[c] >> 16); iw = iw0 + (x_rc[c] & 0xffff);
+                } else {
+                    const int px = idx / XCH;
+                    ih = ih0 + px / HALO_W; iw = iw0 + px % HALO_W;
+                }
                 if (a.reflect) {
                     ih = ih < 0 ? -ih : (ih >= a.H ? 2 * a.H - 2 - ih : ih);
                     iw = iw < 0 ? -iw : (iw >= a.W ? 2 * a.W - 2 - iw : iw);
@@ -146,6 +180,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
         return __builtin_bit_cast(bf16x8, both);
     };
 
+    // halo rows of a lane's two contraction pixels for tap (0, 0), per K step of the patch (patch independent as well)
+    constexpr int KSTEPS = TILE_PX / 32 / WK;
+    auto halo_rows = [&](int kk, int& lo, int& hi) {
+        // lane (g, q, p): contraction rows = linear tile pixels k = 32 kk + 8 g + q (lo) and + 4 (hi)
+        const int k_lo = 32 * kk + 8 * g + q, k_hi = k_lo + 4;
+        // pixels past the tile (TR * TC < 128) carry dz = 0: any row
+        const int m_lo = k_lo < TR * TC ? k_lo : 0, m_hi = k_hi < TR * TC ? k_hi : 0;
+        lo = (m_lo / TC) * STRIDE * HALO_W + (m_lo % TC) * STRIDE;
+        hi = (m_hi / TC) * STRIDE * HALO_W + (m_hi % TC) * STRIDE;
+    };
+    int xl[HOIST ? KSTEPS : 1], xh[HOIST ? KSTEPS : 1];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int i = 0; i < KSTEPS; ++i) halo_rows(wk + i * WK, xl[i], xh[i]);
+    }
+
     int patch = split;
     if (patch < a.n_patches) load_patch(patch);
     for (; patch < a.n_patches; patch += a.splits) {
@@ -153,32 +203,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
         store_patch();
         __syncthreads();
         if (patch + a.splits < a.n_patches) load_patch(patch + a.splits);   // in flight under the MFMAs below
+        // one K step (32 pixels) of the patch for all taps of this workgroup; x_lo / x_hi: halo rows of the lane's two contraction
+        // pixels for tap (0, 0).  (A macro, not a lambda: with the body in a lambda the 32 x 32 instantiation took 256 VGPRs
+        // instead of 148 and its layers ran 98 -> 116 us.)
+#define PPEA_WG_KSTEP(kk_, x_lo_, x_hi_)                                                                                          \
+        {                                                                                                                         \
+            const int k_lo = 32 * (kk_) + 8 * g + q, k_hi = k_lo + 4;                                                             \
+            bf16x8 af[2];                                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i] = tr_z(k_lo, k_hi, (wm * 32 + i * 16) >> 2);                      \
+            _Pragma("unroll") for (int t = 0; t < MAX_TAPS; ++t) {                                                                \
+                if (t < ntap) { /* wave-uniform */                                                                                \
+                    const int off = (r0 + t / KS) * HALO_W + t % KS;                                                              \
+                    bf16x8 bfr[2];                                                                                                \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                 \
+                        bfr[j] = tr_x((x_lo_) + off, (x_hi_) + off, (wn * 32 + j * 16) >> 2);                                     \
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[t][i][j], 0, 0, 0);         \
+                }                                                                                                                 \
+            }                                                                                                                     \
+        }
+        if constexpr (HOIST) {
+            // (and a lambda here: with the macro body the stride-2 instantiations ran 41 -> 61, 48 -> 68, 39 -> 57 us)
+            auto kstep = [&](int kk, int x_lo, int x_hi) { PPEA_WG_KSTEP(kk, x_lo, x_hi) };
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) kstep(wk + ks * WK, xl[ks], xh[ks]);
+        } else {
 #pragma unroll 1
-        for (int kk = wk; kk < TILE_PX / 32; kk += WK) {
-            // lane (g, q, p): contraction rows = linear tile pixels k = 32 kk + 8 g + q (lo) and + 4 (hi)
-            const int k_lo = 32 * kk + 8 * g + q, k_hi = k_lo + 4;
-            // halo rows of the two pixels for tap (0, 0); pixels past the tile (TR * TC < 128) carry dz = 0: any row
-            const int m_lo = k_lo < TR * TC ? k_lo : 0, m_hi = k_hi < TR * TC ? k_hi : 0;
-            const int x_lo = (m_lo / TC) * STRIDE * HALO_W + (m_lo % TC) * STRIDE;
-            const int x_hi = (m_hi / TC) * STRIDE * HALO_W + (m_hi % TC) * STRIDE;
-            bf16x8 af[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = tr_z(k_lo, k_hi, (wm * 32 + i * 16) >> 2);
-#pragma unroll
-            for (int t = 0; t < MAX_TAPS; ++t) {
-                if (t < ntap) {                        // wave-uniform
-                    const int off = (r0 + t / KS) * HALO_W + t % KS;
-                    bf16x8 bfr[2];
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) bfr[j] = tr_x(x_lo + off, x_hi + off, (wn * 32 + j * 16) >> 2);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[t][i][j], 0, 0, 0);
-                }
+            for (int kk = wk; kk < TILE_PX / 32; kk += WK) {
+                // lane (g, q, p): contraction rows = linear tile pixels k = 32 kk + 8 g + q (lo) and + 4 (hi); pixels past the
+                // tile (TR * TC < 128) carry dz = 0: any row
+                const int kl = 32 * kk + 8 * g + q, kh = kl + 4;
+                const int m_lo = kl < TR * TC ? kl : 0, m_hi = kh < TR * TC ? kh : 0;
+                const int x_lo = (m_lo / TC) * STRIDE * HALO_W + (m_lo % TC) * STRIDE;
+                const int x_hi = (m_hi / TC) * STRIDE * HALO_W + (m_hi % TC) * STRIDE;
+                PPEA_WG_KSTEP(kk, x_lo, x_hi)
             }
         }
+#undef PPEA_WG_KSTEP
     }
 
     // partials: C column = li = ci, row = 4 g + e = co; one slab per (split, K-share of the wave)
