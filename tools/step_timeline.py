@@ -23,6 +23,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--replays", type=int, default=5)
     ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--sync_each", action="store_true",
+                    help="synchronize after every replay (exposes the host's submission time at the start of the step)")
     args = ap.parse_args()
     from ppeadepth import _abi, dist as pdist, networks, options, ops, rng, synthetic as synth
     from ppeadepth.trainer import Trainer
@@ -95,6 +97,24 @@ def main():
                        ("pose backward end", "pose_encoder.encoder.conv1.weight")):
         names[key].register_post_accumulate_grad_hook(lambda _p, label=label: mark(label))
 
+    def wrap(obj, attr, label):
+        fn = getattr(obj, attr)
+
+        def wrapped(*a, **k):
+            mark(label + " start")
+            r = fn(*a, **k)
+            mark(label + " end")
+            return r
+        setattr(obj, attr, wrapped)
+
+    wrap(model.encoder, "compute_depth_bins", "student depth bins")
+    wrap(model.encoder.replk, "plan_drop_masks", "student drop masks")
+    wrap(model.mono_encoder, "plan_drop_masks", "teacher drop masks")
+    wrap(model, "predict_poses", "predict_poses")
+    wrap(trainer.depth_bin_tracker, "compute", "tracker.compute")
+    wrap(trainer.depth_bin_tracker, "update", "tracker.update")
+    wrap(trainer, "generate_images_pred", "generate_images_pred")
+
     orig_losses = trainer.compute_losses
 
     def compute_losses(inp, out, is_multi=False):
@@ -128,16 +148,27 @@ def main():
     acc = None
     evs = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     evs[0].record()
-    for _ in range(args.replays):
-        engine.step(inputs)
+    if args.sync_each:
+        for _ in range(args.replays):
+            engine.step(inputs)
+            torch.cuda.synchronize()
+            t = slots[:len(marks)].cpu().double()
+            t = (t - t[0]) / 100.0                        # 100 MHz -> microseconds since "step start"
+            acc = t if acc is None else acc + t
+        evs[1].record()
+        torch.cuda.synchronize()
+        acc = acc / args.replays
+    else:
+        # back to back, as a training loop (and bench.py) replays them: the host submits replay k + 1 while the device runs
+        # replay k; the timestamps are those of the LAST replay (each replay overwrites the slots)
+        for _ in range(args.replays):
+            engine.step(inputs)
+        evs[1].record()
         torch.cuda.synchronize()
         t = slots[:len(marks)].cpu().double()
-        t = (t - t[0]) / 100.0                            # 100 MHz -> microseconds since "step start"
-        acc = t if acc is None else acc + t
-    evs[1].record()
-    torch.cuda.synchronize()
-    acc = acc / args.replays
-    print(f"captured step, B = {B}, {W}x{H}, bf16: {len(marks)} timestamps, mean of {args.replays} replays "
+        acc = (t - t[0]) / 100.0
+    how = "mean of" if args.sync_each else "last of"
+    print(f"captured step, B = {B}, {W}x{H}, bf16: {len(marks)} timestamps, {how} {args.replays} replays "
           f"(replay + synchronize: {evs[0].elapsed_time(evs[1]) / args.replays:.2f} ms each); switches: "
           + " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("PPEA_")))
     print(f"{'ms':>8s}  {'stream':7s} point")
