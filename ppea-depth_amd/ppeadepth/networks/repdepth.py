@@ -30,30 +30,6 @@ POSE_SIDE = os.environ.get("PPEA_POSE_SIDE", "1") == "1"     # pose network (for
 POSE_SIDE_INLINE0 = os.environ.get("PPEA_POSE_SIDE_INLINE0", "1") == "1"
 
 
-class _LateBackward(torch.autograd.Function):
-    """Identity on tensors whose producer graph should run its backward as soon as their gradients exist: `early` (the
-    tensors WITH their graph) is carried along, the inputs are detached copies; backward runs the carried graph itself."""
-
-    @staticmethod
-    def forward(ctx, early, *xs):
-        ctx.early = early
-        return tuple(x.view_as(x) for x in xs)
-
-    @staticmethod
-    def backward(ctx, *gs):
-        early, ctx.early = ctx.early, None
-        pairs = [(e, g) for e, g in zip(early, gs) if g is not None]
-        if pairs:
-            torch.autograd.backward([e for e, _ in pairs], [g for _, g in pairs])
-        return (None,) * (1 + len(gs))
-ASYNC_FLUSH = os.environ.get("PPEA_ASYNC_FLUSH", "1") == "1"   # deferred running-statistics update beside the loss
-BATCHED_POSES = True      # third (no_grad) pose pass replayed instead of recomputed (see _predict_poses_batched)
-POSE_ONE_BATCH = True      # both pairs as one 2B batch with per-pair BN statistics (needs the fused NHWC BN path)
-
-def _g(opt, name, default):
-    return getattr(opt, name, default)
-
-
 class RepDepth(nn.Module):
     def __init__(self, opt):
         super().__init__()
@@ -335,18 +311,6 @@ class RepDepth(nn.Module):
                 for v in mono_outputs.values():          # produced on the side stream, consumed on this one
                     if torch.is_tensor(v) and v.is_cuda:
                         v.record_stream(main)
-            if pose_side is not None:
-                # Autograd runs ready nodes latest-created first, and the pose network was created first: its backward would
-                # be the tail of the step.  The transforms are handed on through a node created HERE, last, on the side stream:
-                # its backward runs the pose network's backward there and then -- at the start of the step's backward, beside
-                # the decoders' (the gradient reaches it from the teacher's loss only; the student's uses T.detach()).
-                keys = [k for k in pose_pred if k[0] == "cam_T_cam" and pose_pred[k].requires_grad]
-                if keys:
-                    with torch.cuda.stream(pose_side):
-                        late = _LateBackward.apply([pose_pred[k] for k in keys],
-                                                   *[pose_pred[k].detach().requires_grad_() for k in keys])
-                    for k, t in zip(keys, late):
-                        outputs[k] = mono_outputs[k] = t
         finally:
             set_deferred(None)
             if book is not None:
