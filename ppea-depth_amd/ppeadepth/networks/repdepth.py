@@ -28,6 +28,13 @@ _ENC_CH = {"b": [128, 256, 512, 1024], "l": [192, 384, 768, 1536]}
 TWO_STREAMS = True
 POSE_SIDE = os.environ.get("PPEA_POSE_SIDE", "1") == "1"     # pose network (forward and backward) on the adapter side stream
 POSE_SIDE_INLINE0 = os.environ.get("PPEA_POSE_SIDE_INLINE0", "1") == "1"
+ASYNC_FLUSH = os.environ.get("PPEA_ASYNC_FLUSH", "1") == "1"   # deferred running-statistics update beside the loss
+BATCHED_POSES = True      # third (no_grad) pose pass replayed instead of recomputed (see _predict_poses_batched)
+POSE_ONE_BATCH = True      # both pairs as one 2B batch with per-pair BN statistics (needs the fused NHWC BN path)
+
+
+def _g(opt, name, default):
+    return getattr(opt, name, default)
 
 
 class RepDepth(nn.Module):
