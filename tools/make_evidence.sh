@@ -28,4 +28,7 @@ python3 tools/dwconv_phases.py 2>/dev/null | grep -v amdgpu > $OUT/${R}_dwconv_p
 (cd tools && python3 bench_dwbn.py 2>/dev/null | grep -v amdgpu > ../$OUT/${R}_dwconv_fused_bn.txt)
 (echo "# row-band kernels only (PPEA_DW_BM=0)"; PPEA_DW_BM=0 python3 tools/bench_dwconv.py --dtype bf16 2>/dev/null | grep -v amdgpu;
  echo "# default dispatch (batch-major variant on the 24 / 12 / 6-row maps, and for the 48-row data gradient)"; python3 tools/bench_dwconv.py --dtype bf16 2>/dev/null | grep -v amdgpu) > $OUT/${R}_dwconv_shapes.txt
+# the captured step's own timeline (timestamps recorded into the graph), current topology and the round-3 one
+python3 tools/step_timeline.py --replays 6 2>/dev/null > $OUT/${R}_step_timeline.txt
+PPEA_POSE_SIDE=0 PPEA_MONO_SIDE=0 python3 tools/step_timeline.py --replays 6 2>/dev/null > $OUT/${R}_step_timeline_before.txt
 echo evidence done
