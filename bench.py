@@ -411,7 +411,11 @@ def main():
                     "algorithmic_bytes_per_launch": bytes_alg,
                     "dgrad_avg_launch_us": round(sum(bwd) / len(bwd) * 1e6 - event_overhead_us, 1) if bwd else None,
                     "dgrad_back_to_back_us": round(replay_us["bwd31"], 1) if "bwd31" in replay_us else None,
-                    "dgrad_name": "dwconv_bm_kernel<31,5,1,48,12,2,4,false> (batch-major variant; M = images)"}
+                    "dgrad_name": "dwconv_bm_kernel<31,5,1,48,12,2,4,false> (batch-major variant; M = images)",
+                    "timing_note": "avg_launch_us = HIP events around each launch INSIDE the step, the other two streams' "
+                                   "kernels sharing the chip; back_to_back_us = the same launch alone.  rocprofv3 --kernel-trace "
+                                   "serialises the step's streams (tools/step_timeline.py), so its average for this kernel "
+                                   "(profiles/*_bench_n1_kernel_stats.csv) lies between the two"}
             if args.dtype == "bf16":
                 # banded-Toeplitz MFMA kernel: (31 rows x 2 chunks + 5) v_mfma_f32_16x16x32_bf16 per 16x16 tile
                 executed = (plane / 256.0) * (31 * 2 + 5) * 2.0 * 16 * 16 * 32
