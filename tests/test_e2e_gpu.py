@@ -880,3 +880,50 @@ def test_step_is_a_pure_function_of_state_inputs_and_seeds(device, bf16):
     for what, a in (("eager 2", e2), ("replay 1", g1), ("replay 2", g2)):
         diff = [k for k in e1 if not torch.equal(e1[k], a[k])]
         assert not diff, (what, len(diff), diff[:6])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bf16", [False, True])
+def test_side_stream_placement_does_not_change_a_bit_of_the_step(device, bf16):
+    """Round 4 moved the pose network, the teacher's loss, the deferred running-statistics update and the one-rank gradient
+    packing between streams (`tools/step_timeline.py`).  Placement must not change arithmetic: the captured step with
+    everything on the side stream (the default) and the eager step with every move switched off agree bit for bit in every loss,
+    output, gradient and post-step state tensor -- a missing wait between two streams would show up here as a difference."""
+    from ppeadepth import dist as pdist, rng, trainer as trainer_mod
+    from ppeadepth.dist import TrainEngine
+    from ppeadepth.networks import repdepth
+    B, H, W = 2, 64, 96
+    inputs = {k: v.to(device) for k, v in synth.make_inputs(B, H, W, smooth=True).items()}
+    saved = (repdepth.POSE_SIDE, repdepth.POSE_SIDE_INLINE0, repdepth.ASYNC_FLUSH, trainer_mod.MONO_LOSS_SIDE, pdist.N1_RANGE_HOOKS)
+
+    def run(moves, graph):
+        (repdepth.POSE_SIDE, repdepth.POSE_SIDE_INLINE0, repdepth.ASYNC_FLUSH, trainer_mod.MONO_LOSS_SIDE,
+         pdist.N1_RANGE_HOOKS) = (moves,) * 5
+        torch.manual_seed(0)
+        opt, model, tr = _build(device, B, H, W, use_checkpoint=True, amp=torch.bfloat16 if bf16 else None)
+        eng = TrainEngine(tr, lr=1e-4, bf16_params=bf16)
+        try:
+            if graph:
+                eng.capture(inputs, warmup=1, restore_state=True)
+            torch.manual_seed(3)
+            random.seed(3)
+            outputs, losses = eng.step(inputs if graph else dict(inputs))
+            torch.cuda.synchronize()
+            res = {"loss:" + k: v.detach().clone() for k, v in losses.items()}
+            res.update({"out:" + str(k): v.detach().clone() for k, v in outputs.items() if torch.is_tensor(v)})
+            res.update({"grad:" + k: v.detach().clone() for k, v in eng.named_grads().items()})
+            res.update({"state:" + k: v.detach().clone() for k, v in model.state_dict().items()})
+            return res
+        finally:
+            rng.set_aug_buffer(None)
+
+    try:
+        plain = run(False, graph=False)
+        moved = run(True, graph=True)
+    finally:
+        (repdepth.POSE_SIDE, repdepth.POSE_SIDE_INLINE0, repdepth.ASYNC_FLUSH, trainer_mod.MONO_LOSS_SIDE,
+         pdist.N1_RANGE_HOOKS) = saved
+        rng.set_mode("device")
+    assert set(plain) == set(moved)
+    diff = [k for k in plain if not torch.equal(plain[k], moved[k])]
+    assert not diff, (len(diff), diff[:8])
